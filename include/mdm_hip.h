@@ -1,0 +1,121 @@
+/* libmdm_hip -- C ABI of the MI355X (gfx950) U-Net denoiser hot path.
+ *
+ * This is the drop-in boundary of the repository: every arithmetic step that
+ * apple/ml-mdm's UNet / NestedUNet forward+backward dispatches to a vendor
+ * library through torch.nn / torch.nn.functional is one entry point here.
+ * The reference has no native boundary of its own (it is pure Python on top of
+ * ATen); the "interface replaced" column therefore cites the Python call site
+ * (paths relative to ml-mdm-matryoshka/ml_mdm/).
+ *
+ * Rules common to all entry points
+ *   - plain pointers + sizes only; device pointers unless stated; no torch types
+ *   - no allocation, no host synchronisation; caller owns every buffer including
+ *     workspaces (sizes come from the *_plan functions, which are host-only)
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream)
+ *   - `dtype` selects the storage type of activations / packed weights:
+ *       MDM_F32 (0)  exact-fp32 MFMA path (v_mfma_f32_16x16x4_f32)  -- parity mode
+ *       MDM_BF16 (1) bf16 storage, fp32 accumulate (v_mfma_f32_16x16x32_bf16)
+ *     parameters, their gradients, normalisation statistics and LSEs are always fp32
+ *   - activations are NHWC: [N, H, W, C] (a linear layer is N=rows, H=W=1)
+ *   - channel counts must be multiples of the 16-byte chunk: 4 (fp32) / 8 (bf16)
+ *   - return value: 0 ok, <0 invalid argument (mdm_last_error() describes it),
+ *     >0 the hipError_t of a failed launch
+ */
+#ifndef MDM_HIP_H_
+#define MDM_HIP_H_
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MDM_F32 = 0, MDM_BF16 = 1 };
+enum { MDM_ACT_NONE = 0, MDM_ACT_GELU = 1, MDM_ACT_DGELU_AUX = 2 };
+
+int mdm_abi_version(void);
+const char* mdm_last_error(void);
+
+/* ---- convolution / linear (implicit GEMM on MFMA) --------------------------------------
+ * replaces nn.Conv2d 3x3 s1/s2 p1 and 1x1 (models/unet.py:199-221, 260-271, 514-532, 632, 751;
+ * models/nested_unet.py:109-128) and nn.Linear (unet.py:206, 264, 605-609, 625-626, 763).
+ *
+ * mdm_pack_weight: reference layout (Cout, Cin, k, k) fp32  ->  w_fwd [Cout][k*k][Cin_pad] and
+ *   (optional) w_dgrad [Cin][k*k flipped][Cout_pad], both of `dtype`.
+ * mdm_conv_fwd:  y = epilogue(conv(x, w_packed)).  epilogue = +bias, act, +res (in this order);
+ *   act == MDM_ACT_GELU writes the pre-activation to y_pre when non-null;
+ *   act == MDM_ACT_DGELU_AUX multiplies by gelu'(aux) (backward through the FFN GELU, unet.py:270).
+ *   The same entry computes the input gradient: pass dy as x and w_dgrad as w_packed
+ *   (transposed = 1 for the gradient of a stride-2 convolution: Ho = 2H, Wo = 2W).
+ * mdm_conv_wgrad: dw (Cout, Cin, k, k) fp32 = sum_m dy[m, :] (x) im2col(x)[m, :]; ws from mdm_conv_wgrad_plan.
+ * mdm_colsum: out[c] = sum_m x[m, c]  (bias gradients); ws from mdm_colsum_plan.
+ */
+int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int ksize, int Cin_pad,
+                    int Cout_pad, int dtype, void* stream);
+int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const void* res, const void* aux, void* y,
+                 void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride,
+                 int transposed, int act, int dtype, void* stream);
+int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes);
+int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, float* ws, int N, int H, int W, int Cin, int Ho,
+                   int Wo, int Cout, int ksize, int stride, int dtype, void* stream);
+int mdm_colsum_plan(int M, int C, int* nblocks, size_t* ws_bytes);
+int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int dtype, void* stream);
+
+/* ---- GroupNorm (+FiLM) (+SiLU), LayerNorm -----------------------------------------------
+ * replaces nn.GroupNorm + F.silu + the FiLM modulation `norm2(h) * (1 + ta) + tb`
+ * (unet.py:224, 233, 259, 268, 878) and nn.LayerNorm on the text states (unet.py:263, 304).
+ *   y = act(GN(x; gamma, beta) * (1 + film[:, :C]) + film[:, C:]),  act: 0 none, 1 SiLU
+ *   stats [N][G][2] = (mean, rstd), coef [N][C][2]: saved by forward, consumed by backward.
+ *   mdm_gn_bwd writes dx, dgamma[C], dbeta[C] and dfilm [N][2C] (when film != NULL).
+ *   ws (fp32) size from mdm_gn_plan (valid for both directions).
+ */
+int mdm_gn_plan(int N, int HW, int C, int G, size_t* ws_bytes);
+int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, const void* film, void* y, float* stats,
+               float* coef, float* ws, int N, int HW, int C, int G, float eps, int act, int dtype, void* stream);
+int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* film,
+               const float* stats, const float* coef, void* dx, float* dgamma, float* dbeta, void* dfilm, float* ws,
+               int N, int HW, int C, int G, int act, int dtype, void* stream);
+int mdm_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int R, int D, float eps,
+               int dtype, void* stream);
+/* ws: fp32 [ceil(R/64)][D][2] */
+int mdm_ln_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, float* dgamma,
+               float* dbeta, float* ws, int R, int D, int dtype, void* stream);
+
+/* ---- fused self + text cross attention ---------------------------------------------------
+ * replaces SelfAttention.attention x2 + the sum (unet.py:276-307): einsum QK^T, fp32 softmax, einsum PV.
+ *   qkv [B, L, 3C] = (q | k | v), kvc [B, S, 2C] = (k_c | v_c) or NULL, mask [B, S] (0/1 floats) or NULL
+ *   out = softmax(q k^T / sqrt(d)) v + softmax(q k_c^T / sqrt(d) masked) v_c          [B, L, C], C = H * d
+ *   out_cross (optional, needed for backward) = the cross term alone; lse_* [B, H, L] fp32.
+ * mdm_attn_bwd overwrites dqkv [B, L, 3C] and dkvc [B, S, 2C]; delta_* are fp32 [B, H, L] scratch.
+ * d must be one of 32, 64, 96, 128.
+ */
+int mdm_attn_fwd(const void* qkv, const void* kvc, const float* mask, void* out, void* out_cross, float* lse_self,
+                 float* lse_cross, int B, int L, int S, int H, int d, int dtype, void* stream);
+int mdm_attn_bwd(const void* qkv, const void* kvc, const float* mask, const void* out, const void* out_cross,
+                 const void* dout, const float* lse_self, const float* lse_cross, float* delta_self,
+                 float* delta_cross, void* dqkv, void* dkvc, int B, int L, int S, int H, int d, int dtype,
+                 void* stream);
+
+/* ---- streaming helpers ---------------------------------------------------------------------
+ * layout conversion at the model boundary (the reference is NCHW fp32, unet.py:971-987),
+ * torch.cat skip connections (unet.py:545-547; dir = 1 is the backward split),
+ * F.interpolate(scale_factor=2) nearest (unet.py:567-569) and its adjoint,
+ * F.silu on the time embedding (unet.py:227, 844), sin/cos timestep embedding (unet.py:834-836),
+ * the masked mean over text tokens (unet.py:854-861), dtype casts.
+ * mdm_elementwise op: 0 out = silu(a); 1 out = b * silu'(a); 2 out = a + b; 3 out = a.
+ */
+int mdm_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int dtype, void* stream);
+int mdm_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cs, int dtype, void* stream);
+int mdm_concat(void* a, void* b, void* out, size_t M, int C1, int C2, int dir, int dtype, void* stream);
+int mdm_upsample2x(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+int mdm_downsum2x(const void* dy, void* dx, int N, int H, int W, int C, int dtype, void* stream);
+int mdm_elementwise(const void* a, const void* b, void* out, size_t n, int op, int dtype, void* stream);
+int mdm_cast(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, void* stream);
+int mdm_sincos_emb(const float* times, const float* freqs, void* out, int B, int half, int dtype, void* stream);
+int mdm_masked_mean(const void* x, const float* mask, void* y, int B, int S, int D, int dtype, void* stream);
+int mdm_masked_mean_bwd(const void* dy, const float* mask, void* dx, int B, int S, int D, int accumulate, int dtype,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDM_HIP_H_ */

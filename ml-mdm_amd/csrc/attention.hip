@@ -1,0 +1,637 @@
+// Fused (flash-style) self + text-cross attention, forward and backward, gfx950 MFMA.
+//
+// Reference semantics (ml_mdm/models/unet.py:276-313, SelfAttention):
+//   q, k, v = split(qkv(norm(x)))                     heads are channel-major: head h = channels [h*d, (h+1)*d)
+//   h_self  = softmax((q*s)^T (k*s)) v ,  s = d^-1/4  (softmax in fp32, unet.py:292)
+//   h_cross = softmax((q*s)^T (k_c*s) masked) v_c     with k_c, v_c = split(kv_cond(norm_cond(cond)))
+//   h = h_self + h_cross                              two *separate* softmaxes (unet.py:302-307)
+// Nothing of size L x L is ever written to HBM; the backward recomputes the
+// probabilities from the saved log-sum-exp of each softmax.
+//
+// Layout: activations are NHWC, so the 1x1-conv output qkv is [B, L, 3C] and a
+// head's rows are strided views (row stride 3C) -- no head split/merge copies.
+//
+// MFMA operand plan (16x16 tiles, fragment = 8 reduction elements per lane,
+// common.hpp).  Forward, per 64-key tile held in LDS:
+//   S^T = K Q^T     A = K rows (LDS, natural [key][d]),   B = Q rows (registers)
+//   O^T = V^T P^T   A = V^T rows (LDS, transposed [d][key]), B = P (registers)
+// With S^T the softmax row of a query lives in one lane column (lane & 15) so
+// the running max / sum need only two cross-quad shuffles, and the P registers
+// are already a valid B fragment for the PV product.  The K rows of key tile kt
+// are read in the permuted order key(kt, r) = (kt>>1)*32 + (r>>2)*8 + (kt&1)*4 + (r&3)
+// so that a lane's 8 probabilities of one PV step are 8 *contiguous* keys of the
+// transposed V tile.
+#include "common.hpp"
+
+namespace mdm {
+
+struct AttnArgs {
+  // forward operands; row (b, i) of tensor X, head h, channel c: X[b * X_bs + i * X_rs + h * d + c]
+  const void* q; size_t q_bs; int q_rs;
+  const void* k; const void* v; size_t k_bs; int k_rs;      // self keys / values (same strides)
+  const void* kc; const void* vc; size_t c_bs; int c_rs;    // cross keys / values, null if absent
+  const float* mask;                                         // [B, S] 0/1 or null
+  void* out; void* out_cross; size_t o_bs; int o_rs;         // out_cross may be null
+  float* lse_self; float* lse_cross;                         // [B, H, L]
+  // backward only
+  const void* dout;                                          // same strides as out
+  const float* delta_self; const float* delta_cross;         // [B, H, L]
+  void* dq;                                                  // strides as q
+  void* dk; void* dv; size_t dk_bs; int dk_rs;               // strides of the gradient of (k, v) being produced
+  int pass;                                                  // dkv kernel: 0 = self keys, 1 = cross keys
+  int B, H, L, S;
+  float scale;                                               // 1/sqrt(d)
+};
+
+template <typename T> __device__ __forceinline__ void frag_from_global(Frag<T>& f, const T* p, bool valid);
+template <> __device__ __forceinline__ void frag_from_global<bf16>(Frag<bf16>& f, const bf16* p, bool valid) {
+  uint4 z = {0u, 0u, 0u, 0u};
+  uint4 r = valid ? *reinterpret_cast<const uint4*>(p) : z;
+  f.v = *reinterpret_cast<bf16x8*>(&r);
+}
+template <> __device__ __forceinline__ void frag_from_global<float>(Frag<float>& f, const float* p, bool valid) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f.lo = valid ? *reinterpret_cast<const f32x4*>(p) : z;
+  f.hi = valid ? *reinterpret_cast<const f32x4*>(p + 4) : z;
+}
+
+// two f32x4 score tiles -> one B fragment (8 consecutive reduction slots)
+template <typename T> __device__ __forceinline__ void frag_from_acc(Frag<T>& f, const f32x4& a, const f32x4& b);
+template <> __device__ __forceinline__ void frag_from_acc<bf16>(Frag<bf16>& f, const f32x4& a, const f32x4& b) {
+  f.v = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+template <> __device__ __forceinline__ void frag_from_acc<float>(Frag<float>& f, const f32x4& a, const f32x4& b) {
+  f.lo = a; f.hi = b;
+}
+
+template <typename T, int D> struct AttnGeom {
+  static constexpr int EPV = Tr<T>::EPV, KSTEPS = Tr<T>::KSTEPS;
+  static constexpr int DS = D / 32;                        // 32-deep mma steps across d
+  static constexpr int DT = D / 16;                        // 16-wide tiles across d
+  static constexpr int NPAN = (DS + KSTEPS - 1) / KSTEPS;  // 128-byte panels of a natural [64][d] tile
+  static constexpr int TPAN = 2 / KSTEPS;                  // panels of a transposed [d][64] tile
+  static constexpr int NAT_BYTES = NPAN * 64 * 128;
+  static constexpr int TR_BYTES = TPAN * D * 128;
+  static constexpr int CPR = D / EPV;                      // chunks per row
+};
+
+// rows [row0, row0+64) of a [rows][d] head view -> LDS natural tile (rows >= nrows zero-filled)
+template <typename T, int D>
+__device__ __forceinline__ void load_nat_tile(char* dst, const T* src, int rs, int row0, int nrows, int tid) {
+  using G = AttnGeom<T, D>;
+  for (int c = tid; c < 64 * G::CPR; c += 256) {
+    const int row = c / G::CPR, cc = c - row * G::CPR;
+    uint4 val = {0u, 0u, 0u, 0u};
+    if (row0 + row < nrows) val = *reinterpret_cast<const uint4*>(src + (size_t)(row0 + row) * rs + cc * G::EPV);
+    *reinterpret_cast<uint4*>(dst + (cc >> 3) * (64 * 128) + lds_chunk_off(row, cc & 7)) = val;
+  }
+}
+// same rows, written transposed: LDS [d][64 rows]
+template <typename T, int D>
+__device__ __forceinline__ void load_tr_tile(char* dst, const T* src, int rs, int row0, int nrows, int tid) {
+  using G = AttnGeom<T, D>;
+  constexpr int NBLK = (64 / G::EPV) * G::CPR;
+  for (int bi = tid; bi < NBLK; bi += 256) {
+    const int kb = bi / G::CPR, cc = bi - kb * G::CPR;
+    Blk<T> blk;
+#pragma unroll
+    for (int e = 0; e < G::EPV; ++e) {
+      const int row = row0 + kb * G::EPV + e;
+      if (row < nrows) blk.load_row(e, src + (size_t)row * rs + cc * G::EPV);
+      else blk.zero_row(e);
+    }
+#pragma unroll
+    for (int c = 0; c < G::EPV; ++c)
+      *reinterpret_cast<uint4*>(dst + (kb >> 3) * (D * 128) + lds_chunk_off(cc * G::EPV + c, kb & 7)) = blk.col(c);
+  }
+}
+
+__device__ __forceinline__ int perm_row(int kt, int r) { return (kt >> 1) * 32 + (r >> 2) * 8 + (kt & 1) * 4 + (r & 3); }
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+template <typename T, int D, int QT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  using G = AttnGeom<T, D>;
+  constexpr int KSTEPS = G::KSTEPS, DS = G::DS, DT = G::DT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + G::NAT_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int quad = lane >> 4, l16 = lane & 15;
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+
+  const T* Q = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * D;
+  Frag<T> qf[QT][DS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qi = q0 + qt * 16 + l16;
+#pragma unroll
+    for (int ks = 0; ks < DS; ++ks) frag_from_global<T>(qf[qt][ks], Q + (size_t)qi * p.q_rs + ks * 32 + quad * 8, qi < p.L);
+  }
+
+  f32x4 res[QT][DT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) res[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int npass = p.kc ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const T* Kp = reinterpret_cast<const T*>(pass ? p.kc : p.k) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
+    const T* Vp = reinterpret_cast<const T*>(pass ? p.vc : p.v) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
+    const int rs = pass ? p.c_rs : p.k_rs;
+    const int nk = pass ? p.S : p.L;
+    const float* mrow = (pass && p.mask) ? p.mask + (size_t)b * p.S : nullptr;
+
+    f32x4 o[QT][DT];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      m_run[qt] = -1e30f; l_run[qt] = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int k0 = 0; k0 < nk; k0 += 64) {
+      __syncthreads();
+      load_nat_tile<T, D>(Ks, Kp, rs, k0, nk, tid);
+      load_tr_tile<T, D>(Vs, Vp, rs, k0, nk, tid);
+      __syncthreads();
+
+      f32x4 s[QT][4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        Frag<T> kf[DS];
+        const int row = perm_row(kt, l16);
+#pragma unroll
+        for (int ks = 0; ks < DS; ++ks) load_frag<T>(kf[ks], Ks + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < DS; ++ks) mma16(s[qt][kt], kf[ks], qf[qt][ks]);
+        }
+      }
+      // scale + mask.  lane holds key positions (kt>>1)*32 + quad*8 + (kt&1)*4 + i
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = k0 + (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
+          bool ok = key < nk;
+          if (ok && mrow) ok = mrow[key] != 0.f;
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) s[qt][kt][i] = ok ? s[qt][kt][i] * p.scale : -1e30f;
+        }
+      Frag<T> pf[QT][2];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float mx = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[qt][kt][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = __expf(m_run[qt] - m_new);
+        m_run[qt] = m_new;
+        float ls = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float sv = s[qt][kt][i];
+            const float e = sv > -1e29f ? __expf(sv - m_new) : 0.f;
+            s[qt][kt][i] = e; ls += e;
+          }
+        l_run[qt] = l_run[qt] * alpha + ls;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+        frag_from_acc<T>(pf[qt][0], s[qt][0], s[qt][1]);
+        frag_from_acc<T>(pf[qt][1], s[qt][2], s[qt][3]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          Frag<T> vf;
+          load_frag<T>(vf, Vs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) mma16(o[qt][dt], vf, pf[qt][hh]);
+        }
+    }
+
+    // finalise this softmax
+    T* OC = (pass && p.out_cross) ? reinterpret_cast<T*>(p.out_cross) + (size_t)b * p.o_bs + (size_t)h * D : nullptr;
+    float* LSE = pass ? p.lse_cross : p.lse_self;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float l = l_run[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      const int qi = q0 + qt * 16 + l16;
+      if (LSE && quad == 0 && qi < p.L) LSE[((size_t)b * p.H + h) * p.L + qi] = m_run[qt] + __logf(l);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const f32x4 val = o[qt][dt] * inv;
+        res[qt][dt] += val;
+        if (OC && qi < p.L) {
+          T* dst = OC + (size_t)qi * p.o_rs + dt * 16 + quad * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dst[i] = from_f32<T>(val[i]);
+        }
+      }
+    }
+  }
+
+  T* O = reinterpret_cast<T*>(p.out) + (size_t)b * p.o_bs + (size_t)h * D;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qi = q0 + qt * 16 + l16;
+    if (qi >= p.L) continue;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      T* dst = O + (size_t)qi * p.o_rs + dt * 16 + quad * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = from_f32<T>(res[qt][dt][i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward pre-pass: delta_self = rowsum(dO * (O - O_cross)), delta_cross = rowsum(dO * O_cross)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void attn_delta_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ oc,
+                                  float* __restrict__ dself, float* __restrict__ dcross, int B, int H, int L, int d,
+                                  size_t o_bs, int o_rs) {
+  const size_t total = (size_t)B * H * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int qi = (int)(i % L);
+    const size_t bh = i / L;
+    const int h = (int)(bh % H), b = (int)(bh / H);
+    const size_t off = (size_t)b * o_bs + (size_t)qi * o_rs + (size_t)h * d;
+    float a = 0.f, c = 0.f;
+    for (int j = 0; j < d; ++j) {
+      const float g = to_f32(dout[off + j]);
+      const float ov = to_f32(out[off + j]);
+      const float cv = oc ? to_f32(oc[off + j]) : 0.f;
+      a += g * (ov - cv); c += g * cv;
+    }
+    dself[i] = a;
+    if (dcross) dcross[i] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward, dQ:   dS^T = P^T o (V dO^T - delta),  dQ^T = K^T dS^T  (both softmaxes accumulate)
+// ---------------------------------------------------------------------------------------
+template <typename T, int D, int QT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+  using G = AttnGeom<T, D>;
+  constexpr int KSTEPS = G::KSTEPS, DS = G::DS, DT = G::DT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + G::NAT_BYTES;
+  char* KTs = smem + 2 * G::NAT_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int quad = lane >> 4, l16 = lane & 15;
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+
+  const T* Q = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * D;
+  const T* DO = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.o_bs + (size_t)h * D;
+  Frag<T> qf[QT][DS], gf[QT][DS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qi = q0 + qt * 16 + l16;
+#pragma unroll
+    for (int ks = 0; ks < DS; ++ks) {
+      frag_from_global<T>(qf[qt][ks], Q + (size_t)qi * p.q_rs + ks * 32 + quad * 8, qi < p.L);
+      frag_from_global<T>(gf[qt][ks], DO + (size_t)qi * p.o_rs + ks * 32 + quad * 8, qi < p.L);
+    }
+  }
+  f32x4 dq[QT][DT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int npass = p.kc ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const T* Kp = reinterpret_cast<const T*>(pass ? p.kc : p.k) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
+    const T* Vp = reinterpret_cast<const T*>(pass ? p.vc : p.v) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
+    const int rs = pass ? p.c_rs : p.k_rs;
+    const int nk = pass ? p.S : p.L;
+    const float* mrow = (pass && p.mask) ? p.mask + (size_t)b * p.S : nullptr;
+    const float* LSE = (pass ? p.lse_cross : p.lse_self) + ((size_t)b * p.H + h) * p.L;
+    const float* DEL = (pass ? p.delta_cross : p.delta_self) + ((size_t)b * p.H + h) * p.L;
+    float lse[QT], del[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int qi = q0 + qt * 16 + l16;
+      lse[qt] = qi < p.L ? LSE[qi] : 1e30f;
+      del[qt] = qi < p.L ? DEL[qi] : 0.f;
+    }
+    for (int k0 = 0; k0 < nk; k0 += 64) {
+      __syncthreads();
+      load_nat_tile<T, D>(Ks, Kp, rs, k0, nk, tid);
+      load_nat_tile<T, D>(Vs, Vp, rs, k0, nk, tid);
+      load_tr_tile<T, D>(KTs, Kp, rs, k0, nk, tid);
+      __syncthreads();
+      f32x4 s[QT][4], dp[QT][4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const int row = perm_row(kt, l16);
+        Frag<T> kf[DS], vf[DS];
+#pragma unroll
+        for (int ks = 0; ks < DS; ++ks) {
+          load_frag<T>(kf[ks], Ks + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+          load_frag<T>(vf[ks], Vs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < DS; ++ks) {
+            mma16(s[qt][kt], kf[ks], qf[qt][ks]);
+            mma16(dp[qt][kt], vf[ks], gf[qt][ks]);
+          }
+        }
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = k0 + (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
+          bool ok = key < nk;
+          if (ok && mrow) ok = mrow[key] != 0.f;
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            const float pr = ok ? __expf(s[qt][kt][i] * p.scale - lse[qt]) : 0.f;
+            s[qt][kt][i] = pr * (dp[qt][kt][i] - del[qt]);
+          }
+        }
+      Frag<T> dsf[QT][2];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        frag_from_acc<T>(dsf[qt][0], s[qt][0], s[qt][1]);
+        frag_from_acc<T>(dsf[qt][1], s[qt][2], s[qt][3]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          Frag<T> ktf;
+          load_frag<T>(ktf, KTs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) mma16(dq[qt][dt], ktf, dsf[qt][hh]);
+        }
+    }
+  }
+  T* DQ = reinterpret_cast<T*>(p.dq) + (size_t)b * p.q_bs + (size_t)h * D;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qi = q0 + qt * 16 + l16;
+    if (qi >= p.L) continue;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      T* dst = DQ + (size_t)qi * p.q_rs + dt * 16 + quad * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = from_f32<T>(dq[qt][dt][i] * p.scale);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward, dK / dV of one key set (self or cross).  Block = 64 keys (16 per wave), loops over
+// 64-query tiles staged in LDS (natural + transposed images of Q and dO).
+//   S = Q K^T (rows = queries, permuted), dP = dO V^T, dS = P o (dP - delta)
+//   dV^T = dO^T P,  dK^T = Q^T dS
+// ---------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+  using G = AttnGeom<T, D>;
+  constexpr int KSTEPS = G::KSTEPS, DS = G::DS, DT = G::DT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* Gs = smem + G::NAT_BYTES;
+  char* QTs = smem + 2 * G::NAT_BYTES;
+  char* GTs = QTs + G::TR_BYTES;
+  float* lse_s = reinterpret_cast<float*>(GTs + G::TR_BYTES);
+  float* del_s = lse_s + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int quad = lane >> 4, l16 = lane & 15;
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int pass = p.pass;
+  const int nk = pass ? p.S : p.L;
+  const int key = blockIdx.x * 64 + wave * 16 + l16;
+
+  const T* Kp = reinterpret_cast<const T*>(pass ? p.kc : p.k) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
+  const T* Vp = reinterpret_cast<const T*>(pass ? p.vc : p.v) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
+  const int rs = pass ? p.c_rs : p.k_rs;
+  bool key_ok = key < nk;
+  Frag<T> kf[DS], vf[DS];
+#pragma unroll
+  for (int ks = 0; ks < DS; ++ks) {
+    frag_from_global<T>(kf[ks], Kp + (size_t)key * rs + ks * 32 + quad * 8, key_ok);
+    frag_from_global<T>(vf[ks], Vp + (size_t)key * rs + ks * 32 + quad * 8, key_ok);
+  }
+  bool key_live = key_ok;
+  if (key_ok && pass && p.mask) key_live = p.mask[(size_t)b * p.S + key] != 0.f;
+
+  const T* Q = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * D;
+  const T* DO = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.o_bs + (size_t)h * D;
+  const float* LSE = (pass ? p.lse_cross : p.lse_self) + ((size_t)b * p.H + h) * p.L;
+  const float* DEL = (pass ? p.delta_cross : p.delta_self) + ((size_t)b * p.H + h) * p.L;
+
+  f32x4 dk[DT], dv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int q0 = 0; q0 < p.L; q0 += 64) {
+    __syncthreads();
+    load_nat_tile<T, D>(Qs, Q, p.q_rs, q0, p.L, tid);
+    load_nat_tile<T, D>(Gs, DO, p.o_rs, q0, p.L, tid);
+    load_tr_tile<T, D>(QTs, Q, p.q_rs, q0, p.L, tid);
+    load_tr_tile<T, D>(GTs, DO, p.o_rs, q0, p.L, tid);
+    if (tid < 64) {
+      const int qi = q0 + tid;
+      lse_s[tid] = qi < p.L ? LSE[qi] : 1e30f;
+      del_s[tid] = qi < p.L ? DEL[qi] : 0.f;
+    }
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int row = perm_row(kt, l16);
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < DS; ++ks) {
+        Frag<T> a, g;
+        load_frag<T>(a, Qs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+        load_frag<T>(g, Gs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+        mma16(s[kt], a, kf[ks]);
+        mma16(dp[kt], g, vf[ks]);
+      }
+    }
+    // lane: key = l16 (column), query positions (kt>>1)*32 + quad*8 + (kt&1)*4 + i
+    f32x4 pr[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int qp = (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
+        const float pv = key_live ? __expf(s[kt][i] * p.scale - lse_s[qp]) : 0.f;
+        pr[kt][i] = pv;
+        s[kt][i] = pv * (dp[kt][i] - del_s[qp]);
+      }
+    Frag<T> pf[2], dsf[2];
+    frag_from_acc<T>(pf[0], pr[0], pr[1]);
+    frag_from_acc<T>(pf[1], pr[2], pr[3]);
+    frag_from_acc<T>(dsf[0], s[0], s[1]);
+    frag_from_acc<T>(dsf[1], s[2], s[3]);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        Frag<T> a, g;
+        load_frag<T>(g, GTs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
+        load_frag<T>(a, QTs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
+        mma16(dv[dt], g, pf[hh]);
+        mma16(dk[dt], a, dsf[hh]);
+      }
+  }
+  if (key_ok) {
+    T* DK = reinterpret_cast<T*>(p.dk) + (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key * p.dk_rs;
+    T* DV = reinterpret_cast<T*>(p.dv) + (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key * p.dk_rs;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        DK[dt * 16 + quad * 4 + i] = from_f32<T>(dk[dt][i] * p.scale);
+        DV[dt * 16 + quad * 4 + i] = from_f32<T>(dv[dt][i]);
+      }
+  }
+}
+
+}  // namespace mdm
+
+using namespace mdm;
+
+template <typename K>
+static void set_smem(K kern, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <typename T, int D>
+static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
+  using G = AttnGeom<T, D>;
+  constexpr int QT = 2;
+  constexpr int smem = G::NAT_BYTES + G::TR_BYTES;
+  auto kern = attn_fwd_kernel<T, D, QT>;
+  static bool done = false;
+  if (!done) { set_smem(kern, smem); done = true; }
+  dim3 grid((a.L + 64 * QT - 1) / (64 * QT), a.B * a.H);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  MDM_LAUNCH_STATUS();
+}
+
+template <typename T, int D>
+static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int dc_rs, hipStream_t st) {
+  using G = AttnGeom<T, D>;
+  constexpr int QT = 2;
+  constexpr int smem_q = 2 * G::NAT_BYTES + G::TR_BYTES;
+  constexpr int smem_kv = 2 * G::NAT_BYTES + 2 * G::TR_BYTES + 512;
+  auto kq = attn_bwd_dq_kernel<T, D, QT>;
+  auto kkv = attn_bwd_dkv_kernel<T, D>;
+  static bool done = false;
+  if (!done) { set_smem(kq, smem_q); set_smem(kkv, smem_kv); done = true; }
+  hipLaunchKernelGGL(kq, dim3((a.L + 64 * QT - 1) / (64 * QT), a.B * a.H), dim3(256), smem_q, st, a);
+  a.pass = 0;
+  hipLaunchKernelGGL(kkv, dim3((a.L + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);
+  if (a.kc) {
+    a.pass = 1; a.dk = dkc; a.dv = dvc; a.dk_bs = dc_bs; a.dk_rs = dc_rs;
+    hipLaunchKernelGGL(kkv, dim3((a.S + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);
+  }
+  MDM_LAUNCH_STATUS();
+}
+
+// qkv: [B, L, 3C] (q | k | v along channels), kvc: [B, S, 2C] (k_c | v_c) or null, mask [B, S] or null.
+// out, out_cross: [B, L, C]; lse_*: [B, H, L] fp32.  C = H * d, d in {32, 64, 96, 128}.
+extern "C" int mdm_attn_fwd(const void* qkv, const void* kvc, const float* mask, void* out, void* out_cross,
+                            float* lse_self, float* lse_cross, int B, int L, int S, int H, int d, int dtype,
+                            void* stream) {
+  MDM_CHECK_ARG(qkv && out);
+  MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
+  MDM_CHECK_ARG(B > 0 && L > 0 && H > 0);
+  MDM_CHECK_ARG(!kvc || S > 0);
+  const int C = H * d;
+  const size_t es = dtype == DT_F32 ? 4 : 2;
+  AttnArgs a = {};
+  a.q = qkv; a.q_bs = (size_t)L * 3 * C; a.q_rs = 3 * C;
+  a.k = (const char*)qkv + (size_t)C * es; a.v = (const char*)qkv + (size_t)2 * C * es; a.k_bs = a.q_bs; a.k_rs = 3 * C;
+  if (kvc) { a.kc = kvc; a.vc = (const char*)kvc + (size_t)C * es; a.c_bs = (size_t)S * 2 * C; a.c_rs = 2 * C; }
+  a.mask = mask; a.out = out; a.out_cross = out_cross; a.o_bs = (size_t)L * C; a.o_rs = C;
+  a.lse_self = lse_self; a.lse_cross = lse_cross;
+  a.B = B; a.H = H; a.L = L; a.S = S; a.scale = 1.0f / sqrtf((float)d);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define MDM_ATTN_FWD(DD)                                                                        \
+  case DD: return dtype == DT_F32 ? attn_fwd_launch<float, DD>(a, st) : attn_fwd_launch<bf16, DD>(a, st);
+  switch (d) {
+    MDM_ATTN_FWD(32) MDM_ATTN_FWD(64) MDM_ATTN_FWD(96) MDM_ATTN_FWD(128)
+    default: MDM_CHECK_ARG(!"unsupported head dim");
+  }
+#undef MDM_ATTN_FWD
+  return -1;
+}
+
+// dqkv [B, L, 3C], dkvc [B, S, 2C] are fully overwritten.  delta_* : fp32 workspaces [B, H, L].
+extern "C" int mdm_attn_bwd(const void* qkv, const void* kvc, const float* mask, const void* out,
+                            const void* out_cross, const void* dout, const float* lse_self, const float* lse_cross,
+                            float* delta_self, float* delta_cross, void* dqkv, void* dkvc, int B, int L, int S,
+                            int H, int d, int dtype, void* stream) {
+  MDM_CHECK_ARG(qkv && out && dout && lse_self && delta_self && dqkv);
+  MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
+  MDM_CHECK_ARG(!kvc || (out_cross && lse_cross && delta_cross && dkvc && S > 0));
+  const int C = H * d;
+  const size_t es = dtype == DT_F32 ? 4 : 2;
+  AttnArgs a = {};
+  a.q = qkv; a.q_bs = (size_t)L * 3 * C; a.q_rs = 3 * C;
+  a.k = (const char*)qkv + (size_t)C * es; a.v = (const char*)qkv + (size_t)2 * C * es; a.k_bs = a.q_bs; a.k_rs = 3 * C;
+  if (kvc) { a.kc = kvc; a.vc = (const char*)kvc + (size_t)C * es; a.c_bs = (size_t)S * 2 * C; a.c_rs = 2 * C; }
+  a.mask = mask; a.o_bs = (size_t)L * C; a.o_rs = C;
+  a.lse_self = const_cast<float*>(lse_self); a.lse_cross = const_cast<float*>(lse_cross);
+  a.dout = dout; a.delta_self = delta_self; a.delta_cross = delta_cross;
+  a.dq = dqkv; a.dk = (char*)dqkv + (size_t)C * es; a.dv = (char*)dqkv + (size_t)2 * C * es;
+  a.dk_bs = a.q_bs; a.dk_rs = 3 * C;
+  a.B = B; a.H = H; a.L = L; a.S = S; a.scale = 1.0f / sqrtf((float)d);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t total = (size_t)B * H * L;
+  const int nb = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)(kvc ? out_cross : nullptr), delta_self, kvc ? delta_cross : nullptr, B, H, L, d, a.o_bs, a.o_rs);
+  else
+    hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)dout, (const bf16*)out, (const bf16*)(kvc ? out_cross : nullptr), delta_self, kvc ? delta_cross : nullptr, B, H, L, d, a.o_bs, a.o_rs);
+  void* dkc = dkvc;
+  void* dvc = kvc ? (char*)dkvc + (size_t)C * es : nullptr;
+#define MDM_ATTN_BWD(DD)                                                                                    \
+  case DD: return dtype == DT_F32 ? attn_bwd_launch<float, DD>(a, dkc, dvc, (size_t)S * 2 * C, 2 * C, st)  \
+                                  : attn_bwd_launch<bf16, DD>(a, dkc, dvc, (size_t)S * 2 * C, 2 * C, st);
+  switch (d) {
+    MDM_ATTN_BWD(32) MDM_ATTN_BWD(64) MDM_ATTN_BWD(96) MDM_ATTN_BWD(128)
+    default: MDM_CHECK_ARG(!"unsupported head dim");
+  }
+#undef MDM_ATTN_BWD
+  return -1;
+}

@@ -1,0 +1,210 @@
+// Shared device-side helpers for the gfx950 (CDNA4) kernels of libmdm_hip.
+//
+// Conventions used by every kernel in this directory:
+//   * activations are NHWC ("pixel-major"): [N, H, W, C] with C contiguous
+//   * T is the storage type of activations and packed weights: float or __bf16
+//   * all reductions / accumulators are fp32
+//   * a "chunk" is 16 bytes = EPV elements of T (8 bf16 or 4 fp32)
+//   * wavefront = 64 lanes, hard-coded
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mdm {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+template <typename T> struct Tr;
+template <> struct Tr<float> {
+  static constexpr int EPV = 4;       // elements per 16-byte chunk
+  static constexpr int BK = 32;       // GEMM k-tile in elements (128 B rows)
+  static constexpr int KSTEPS = 1;    // generic 32-deep mma steps per k-tile
+};
+template <> struct Tr<bf16> {
+  static constexpr int EPV = 8;
+  static constexpr int BK = 64;
+  static constexpr int KSTEPS = 2;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// ---------------------------------------------------------------------------
+// 16-byte chunk <-> fp32 lanes
+// ---------------------------------------------------------------------------
+template <typename T> struct Chunk;  // EPV values of T held as fp32
+template <> struct Chunk<float> {
+  float v[4];
+  __device__ __forceinline__ void load(const float* p) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct Chunk<bf16> {
+  float v[8];
+  __device__ __forceinline__ void load(const bf16* p) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+  __device__ __forceinline__ void store(bf16* p) const {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// MFMA fragments. A "fragment" is 8 consecutive reduction-dim elements owned by
+// a lane; lane l owns row/col (l & 15) and reduction slots (l >> 4) * 8 + j.
+// bf16 : one v_mfma_f32_16x16x32_bf16 consumes a fragment pair.
+// fp32 : eight v_mfma_f32_16x16x4_f32 consume it (slot j of every quad per
+//        instruction) -- exact fp32, used by the parity ("fp32") mode.
+// Output mapping (both): acc[i] = D[row = (l >> 4) * 4 + i][col = l & 15] for
+// D = A * B with A the first operand.
+// ---------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16> {
+  bf16x8 v;
+  __device__ __forceinline__ void load_lds(const char* p0, const char* /*p1*/) {
+    v = *reinterpret_cast<const bf16x8*>(p0);
+  }
+};
+template <> struct Frag<float> {
+  f32x4 lo, hi;
+  __device__ __forceinline__ void load_lds(const char* p0, const char* p1) {
+    lo = *reinterpret_cast<const f32x4*>(p0);
+    hi = *reinterpret_cast<const f32x4*>(p1);
+  }
+};
+
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[j], b.lo[j], acc, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[j], b.hi[j], acc, 0, 0, 0);
+}
+
+// LDS tile addressing shared by the GEMM-shaped kernels: rows of 128 bytes (8
+// chunks), chunk index XOR-swizzled with (row & 7) so that the 16-lane groups
+// of ds_read_b128 land on 16 distinct 16-byte slots.
+__device__ __forceinline__ int lds_chunk_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ (row & 7)) << 4);
+}
+
+// Fragment read for mma step `ks` (32 reduction elements per step) of row `row`.
+template <typename T>
+__device__ __forceinline__ void load_frag(Frag<T>& f, const char* tile, int row, int ks, int quad);
+template <>
+__device__ __forceinline__ void load_frag<bf16>(Frag<bf16>& f, const char* tile, int row, int ks, int quad) {
+  f.load_lds(tile + lds_chunk_off(row, ks * 4 + quad), nullptr);
+}
+template <>
+__device__ __forceinline__ void load_frag<float>(Frag<float>& f, const char* tile, int row, int /*ks*/, int quad) {
+  f.load_lds(tile + lds_chunk_off(row, 2 * quad), tile + lds_chunk_off(row, 2 * quad + 1));
+}
+
+// EPV x EPV register block with an in-register transpose: rows are 16-byte
+// chunks loaded from HBM (reduction index slow), col(c) is the 16-byte chunk of
+// the transposed block.  Used wherever an MFMA operand is reduction-major in HBM.
+template <typename T> struct Blk;  // EPV x EPV register block + transpose
+template <> struct Blk<float> {
+  f32x4 r[4];
+  __device__ __forceinline__ void zero_row(int i) { r[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ void load_row(int i, const float* p) { r[i] = *reinterpret_cast<const f32x4*>(p); }
+  // row c of the transposed block: elements (r[0][c], r[1][c], r[2][c], r[3][c])
+  __device__ __forceinline__ uint4 col(int c) const {
+    f32x4 o = {r[0][c], r[1][c], r[2][c], r[3][c]};
+    return *reinterpret_cast<uint4*>(&o);
+  }
+};
+template <> struct Blk<bf16> {
+  uint4 r[8];
+  __device__ __forceinline__ void zero_row(int i) { r[i] = uint4{0u, 0u, 0u, 0u}; }
+  __device__ __forceinline__ void load_row(int i, const bf16* p) { r[i] = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ uint32_t word(const uint4& v, int i) const {
+    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+  }
+  __device__ __forceinline__ uint4 col(int c) const {
+    uint32_t o[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const uint32_t a = word(r[2 * pp], c >> 1), b = word(r[2 * pp + 1], c >> 1);
+      o[pp] = (c & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+    }
+    return uint4{o[0], o[1], o[2], o[3]};
+  }
+};
+
+// wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+// d silu(z) / dz
+__device__ __forceinline__ float dsilu_f(float z) {
+  float s = 1.f / (1.f + __expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float z) {
+  float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752f));
+  float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
+  return cdf + z * pdf;
+}
+
+// XCD-aware, bijective remap of a 1-D block id: consecutive logical ids land on
+// the same XCD (hardware places block b on XCD b % 8) so neighbouring tiles that
+// share operand panels hit the same L2. Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+}  // namespace mdm
+
+// host-side status helpers --------------------------------------------------
+#define MDM_CHECK_ARG(cond)                                                                      \
+  do {                                                                                           \
+    if (!(cond)) {                                                                               \
+      mdm_set_error(__FILE__, __LINE__, #cond);                                                  \
+      return -1;                                                                                 \
+    }                                                                                            \
+  } while (0)
+#define MDM_LAUNCH_STATUS()                                                                      \
+  do {                                                                                           \
+    hipError_t e__ = hipGetLastError();                                                          \
+    if (e__ != hipSuccess) {                                                                     \
+      mdm_set_error(__FILE__, __LINE__, hipGetErrorString(e__));                                 \
+      return (int)e__;                                                                           \
+    }                                                                                            \
+    return 0;                                                                                    \
+  } while (0)
+
+extern "C" void mdm_set_error(const char* file, int line, const char* what);

@@ -1,0 +1,124 @@
+"""Build + ctypes binding of libmdm_hip.so (the C ABI declared in include/mdm_hip.h).
+
+The ctypes signatures are generated from the header itself, so the header is the
+single source of truth for the boundary.  There is deliberately no fallback: if
+the shared library is missing or a call fails, we raise.
+"""
+import ctypes
+import os
+import re
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+HEADER = os.path.join(_ROOT, "include", "mdm_hip.h")
+LIB_PATH = os.path.join(_HERE, "libmdm_hip.so")
+SOURCES = ["gemm_conv.hip", "norm.hip", "attention.hip", "elementwise.hip", "optim.hip"]
+
+_lock = threading.Lock()
+_lib = None
+
+
+class MdmHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every HIP source for gfx950 into ml-mdm_amd/mdm_hip/libmdm_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, "common.hpp")]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if (not force) and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in (s, deps[-1])):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        if verbose:
+            print("[mdm_hip] " + " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise MdmHipError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if verbose:
+        print("[mdm_hip] " + " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise MdmHipError("link failed:\n" + r.stdout.decode(errors="replace"))
+    return LIB_PATH
+
+
+_CTYPES = {
+    "int": ctypes.c_int,
+    "float": ctypes.c_float,
+    "size_t": ctypes.c_size_t,
+}
+
+
+def _ctype_of(decl: str):
+    decl = decl.strip()
+    if "*" in decl:
+        base = decl.replace("const", "").split("*")[0].strip()
+        if base == "char":
+            return ctypes.c_char_p
+        return ctypes.c_void_p
+    base = decl.replace("const", "").split()[0]
+    return _CTYPES[base]
+
+
+def header_prototypes(path: str = HEADER):
+    """[(name, restype, [argtypes], [argnames])] for every function declared in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//.*", "", text)
+    protos = []
+    for m in re.finditer(r"^\s*([A-Za-z_][\w\s\*]*?)\b(mdm_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.M | re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        argtypes, argnames = [], []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                argnames.append(re.split(r"[\s\*]+", a)[-1])
+                argtypes.append(_ctype_of(a))
+        restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+        protos.append((name, restype, argtypes, argnames))
+    return protos
+
+
+def lib():
+    """The loaded library; raises MdmHipError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MdmHipError(
+                "libmdm_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "-- there is no CPU fallback for the product path." % LIB_PATH
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, restype, argtypes, _ in header_prototypes():
+            fn = getattr(handle, name)  # AttributeError if the header and the library drift
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().mdm_last_error()
+        raise MdmHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,611 @@
+"""torch.autograd bindings of the libmdm_hip C ABI (include/mdm_hip.h).
+
+PyTorch is used here for device memory (tensors as buffers), the current HIP
+stream and the autograd tape only; every arithmetic step is a call into the
+shared library through raw pointers.  Activations are NHWC tensors
+``[N, H, W, C]`` (or ``[rows, C]`` for linear layers) of the compute dtype
+(``torch.float32`` = exact parity mode, ``torch.bfloat16`` = throughput mode).
+Parameters stay fp32 in the reference's layout; packed copies for the kernels
+are cached per parameter version.
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise _lib.MdmHipError("unsupported activation dtype %s" % t.dtype)
+
+
+def _epv(t: torch.Tensor) -> int:
+    return 4 if t.dtype == torch.float32 else 8
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise _lib.MdmHipError(
+            "mdm_hip ops run only on an MI355X (got a %s tensor); there is no CPU fallback" % t.device
+        )
+
+
+def _f32_ws(nbytes: int, device):
+    return torch.empty((max(int(nbytes), 4) + 3) // 4, dtype=torch.float32, device=device)
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# packed-weight cache
+# --------------------------------------------------------------------------------------
+_wcache = weakref.WeakKeyDictionary()
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
+    """(w_fwd, w_dgrad, bias_padded, Cin_pad, Cout_pad) for a reference-layout weight
+    ``(Cout, Cin, k, k)`` or ``(Cout, Cin)``; refreshed when the parameter version changes."""
+    key = dtype
+    ent = _wcache.get(weight)
+    ver = (weight._version, None if bias is None else bias._version, weight.data_ptr())
+    if ent is not None and key in ent and ent[key][0] == ver:
+        return ent[key][1]
+    _require_gpu(weight)
+    L = _lib.lib()
+    cout, cin = weight.shape[0], weight.shape[1]
+    ks = weight.shape[2] if weight.dim() == 4 else 1
+    epv = 4 if dtype == torch.float32 else 8
+    cin_pad, cout_pad = _round_up(cin, epv), _round_up(cout, epv)
+    taps = ks * ks
+    w32 = _c(weight.detach().float())
+    wf = torch.empty(cout_pad * taps * cin_pad, dtype=dtype, device=weight.device)
+    need_d = cin_pad == cin
+    wd = torch.empty(cin * taps * cout_pad, dtype=dtype, device=weight.device) if need_d else None
+    if cout_pad != cout:
+        wf.zero_()
+    _lib.check(
+        L.mdm_pack_weight(_p(w32), _p(wf), _p(wd), cout, cin, ks, cin_pad, cout_pad, F32 if dtype == torch.float32 else BF16, _stream()),
+        "mdm_pack_weight",
+    )
+    bp = None
+    if bias is not None:
+        bp = bias.detach().float()
+        if cout_pad != cout:
+            bp = torch.cat([bp, bp.new_zeros(cout_pad - cout)])
+        bp = _c(bp)
+    val = (wf, wd, bp, cin_pad, cout_pad)
+    if ent is None:
+        ent = {}
+        _wcache[weight] = ent
+    ent[key] = (ver, val)
+    return val
+
+
+# --------------------------------------------------------------------------------------
+# raw launches
+# --------------------------------------------------------------------------------------
+def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, stride, transposed, act):
+    _lib.check(
+        _lib.lib().mdm_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(aux), _p(y), _p(ypre), N, H, W, Cin, Ho, Wo, Cout,
+                                ks, stride, transposed, act, _dt(x), _stream()),
+        "mdm_conv_fwd",
+    )
+
+
+def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride):
+    L = _lib.lib()
+    splits = ctypes.c_int(0)
+    wsb = ctypes.c_size_t(0)
+    M, K = N * Ho * Wo, ks * ks * Cin
+    _lib.check(L.mdm_conv_wgrad_plan(M, Cout, K, _dt(x), ctypes.byref(splits), ctypes.byref(wsb)), "mdm_conv_wgrad_plan")
+    ws = _f32_ws(wsb.value, x.device)
+    dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device)
+    _lib.check(L.mdm_conv_wgrad(_p(x), _p(dy), _p(dw), _p(ws), N, H, W, Cin, Ho, Wo, Cout, ks, stride, _dt(x), _stream()),
+               "mdm_conv_wgrad")
+    return dw
+
+
+def _colsum_launch(x2d, M, C):
+    L = _lib.lib()
+    nb = ctypes.c_int(0)
+    wsb = ctypes.c_size_t(0)
+    _lib.check(L.mdm_colsum_plan(M, C, ctypes.byref(nb), ctypes.byref(wsb)), "mdm_colsum_plan")
+    ws = _f32_ws(wsb.value, x2d.device)
+    out = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    _lib.check(L.mdm_colsum(_p(x2d), _p(out), _p(ws), M, C, _dt(x2d), _stream()), "mdm_colsum")
+    return out
+
+
+def _geom(x, ks, stride):
+    """x: [N,H,W,C] or [R,C] -> (N,H,W,Ho,Wo)"""
+    if x.dim() == 2:
+        return x.shape[0], 1, 1, 1, 1
+    N, H, W = x.shape[0], x.shape[1], x.shape[2]
+    if ks == 1:
+        return N, H, W, H, W
+    return N, H, W, (H - 1) // stride + 1, (W - 1) // stride + 1
+
+
+def _out_shape(x, Ho, Wo, C):
+    return (x.shape[0], C) if x.dim() == 2 else (x.shape[0], Ho, Wo, C)
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv(x, weight) + bias (+ residual).  3x3 (stride 1/2, pad 1), 1x1, or linear ([R, Cin])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, stride):
+        _require_gpu(x)
+        x = _c(x)
+        residual = _c(residual)
+        ks = weight.shape[2] if weight.dim() == 4 else 1
+        wf, wd, bp, cin_pad, cout_pad = packed_weight(weight, bias, x.dtype)
+        if x.shape[-1] != cin_pad:
+            raise _lib.MdmHipError("conv input has %d channels, packed weight expects %d" % (x.shape[-1], cin_pad))
+        N, H, W, Ho, Wo = _geom(x, ks, stride)
+        y = torch.empty(_out_shape(x, Ho, Wo, cout_pad), dtype=x.dtype, device=x.device)
+        _conv_launch(x, wf, bp, residual, None, y, None, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, 0, 0)
+        ctx.save_for_backward(x, weight, bias)
+        ctx.stride, ctx.ks = stride, ks
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        dy = _c(dy)
+        ks, stride = ctx.ks, ctx.stride
+        wf, wd, bp, cin_pad, cout_pad = packed_weight(weight, bias, x.dtype)
+        cout, cin = weight.shape[0], weight.shape[1]
+        N, H, W, Ho, Wo = _geom(x, ks, stride)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if wd is None:
+                raise _lib.MdmHipError("input gradient requested for a channel-padded convolution")
+            dx = torch.empty_like(x)
+            if ks == 3 and stride == 2:
+                _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, 3, 1, 1, 0)
+            else:
+                _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, ks, 1, 0, 0)
+        if ctx.needs_input_grad[1]:
+            dwp = _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride)
+            if cout_pad != cout or cin_pad != cin:
+                dwp = dwp[:cout, :cin].contiguous()
+            dw = dwp.view(weight.shape)
+        if bias is not None and ctx.needs_input_grad[2]:
+            db = _colsum_launch(dy, N * Ho * Wo, cout_pad)[:cout]
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres, None
+
+
+def conv(x, weight, bias=None, residual=None, stride=1):
+    return ConvFn.apply(x, weight, bias, residual, stride)
+
+
+def linear(x, weight, bias=None, residual=None):
+    shp = x.shape
+    y = ConvFn.apply(x.reshape(-1, shp[-1]), weight, bias, None if residual is None else residual.reshape(-1, weight.shape[0]), 1)
+    return y.reshape(*shp[:-1], weight.shape[0])
+
+
+class FFNFn(torch.autograd.Function):
+    """y = W2 gelu(W1 x + b1) + b2 + residual  (1x1 convs; unet.py:266-272, 311-312)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual):
+        _require_gpu(x)
+        x, residual = _c(x), _c(residual)
+        wf1, _, bp1, c_in, c_hid = packed_weight(w1, b1, x.dtype)
+        wf2, _, bp2, _, c_out = packed_weight(w2, b2, x.dtype)
+        N, H, W, _, _ = _geom(x, 1, 1)
+        keep = torch.is_grad_enabled()
+        pre = torch.empty(_out_shape(x, H, W, c_hid), dtype=x.dtype, device=x.device) if keep else None
+        a = torch.empty(_out_shape(x, H, W, c_hid), dtype=x.dtype, device=x.device)
+        _conv_launch(x, wf1, bp1, None, None, a, pre, N, H, W, c_in, H, W, c_hid, 1, 1, 0, 1)
+        y = torch.empty(_out_shape(x, H, W, c_out), dtype=x.dtype, device=x.device)
+        _conv_launch(a, wf2, bp2, residual, None, y, None, N, H, W, c_hid, H, W, c_out, 1, 1, 0, 0)
+        ctx.save_for_backward(x, w1, b1, w2, b2, pre, a)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2, b2, pre, a = ctx.saved_tensors
+        dy = _c(dy)
+        _, wd1, _, c_in, c_hid = packed_weight(w1, b1, x.dtype)
+        _, wd2, _, _, c_out = packed_weight(w2, b2, x.dtype)
+        N, H, W, _, _ = _geom(x, 1, 1)
+        M = N * H * W
+        dpre = torch.empty_like(pre)
+        _conv_launch(dy, wd2, None, None, pre, dpre, None, N, H, W, c_out, H, W, c_hid, 1, 1, 0, 2)
+        dw2 = _wgrad_launch(a, dy, N, H, W, c_hid, H, W, c_out, 1, 1).view(w2.shape)
+        db2 = _colsum_launch(dy, M, c_out)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _conv_launch(dpre, wd1, None, None, None, dx, None, N, H, W, c_hid, H, W, c_in, 1, 1, 0, 0)
+        dw1 = _wgrad_launch(x, dpre, N, H, W, c_in, H, W, c_hid, 1, 1).view(w1.shape)
+        db1 = _colsum_launch(dpre, M, c_hid)
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[5]) else None
+        return dx, dw1, db1, dw2, db2, dres
+
+
+def ffn(x, w1, b1, w2, b2, residual):
+    return FFNFn.apply(x, w1, b1, w2, b2, residual)
+
+
+# --------------------------------------------------------------------------------------
+# normalisation
+# --------------------------------------------------------------------------------------
+def _gn_ws(N, HW, C, G, device):
+    wsb = ctypes.c_size_t(0)
+    _lib.check(_lib.lib().mdm_gn_plan(N, HW, C, G, ctypes.byref(wsb)), "mdm_gn_plan")
+    return _f32_ws(wsb.value, device)
+
+
+class GroupNormFn(torch.autograd.Function):
+    """y = act(GroupNorm(x) * (1 + film[:, :C]) + film[:, C:]);  act in {0: none, 1: SiLU}."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, film, groups, eps, act):
+        _require_gpu(x)
+        x, film = _c(x), _c(film)
+        N, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (N * C)
+        g32, b32 = _c(gamma.detach().float()), _c(beta.detach().float())
+        y = torch.empty_like(x)
+        stats = torch.empty((N, groups, 2), dtype=torch.float32, device=x.device)
+        coef = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+        ws = _gn_ws(N, HW, C, groups, x.device)
+        _lib.check(
+            _lib.lib().mdm_gn_fwd(_p(x), _p(g32), _p(b32), _p(film), _p(y), _p(stats), _p(coef), _p(ws), N, HW, C,
+                                  groups, float(eps), act, _dt(x), _stream()),
+            "mdm_gn_fwd",
+        )
+        ctx.save_for_backward(x, gamma, beta, film, stats, coef)
+        ctx.groups, ctx.act = groups, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, film, stats, coef = ctx.saved_tensors
+        dy = _c(dy)
+        N, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (N * C)
+        g32, b32 = _c(gamma.detach().float()), _c(beta.detach().float())
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        dfilm = torch.empty_like(film) if film is not None else None
+        ws = _gn_ws(N, HW, C, ctx.groups, x.device)
+        _lib.check(
+            _lib.lib().mdm_gn_bwd(_p(dy), _p(x), _p(g32), _p(b32), _p(film), _p(stats), _p(coef), _p(dx), _p(dgamma),
+                                  _p(dbeta), _p(dfilm), _p(ws), N, HW, C, ctx.groups, ctx.act, _dt(x), _stream()),
+            "mdm_gn_bwd",
+        )
+        return dx, dgamma, dbeta, dfilm, None, None, None
+
+
+def group_norm(x, gamma, beta, groups, eps=1e-5, film=None, silu=False):
+    return GroupNormFn.apply(x, gamma, beta, film, groups, eps, 1 if silu else 0)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _require_gpu(x)
+        x = _c(x)
+        D = x.shape[-1]
+        R = x.numel() // D
+        g32, b32 = _c(gamma.detach().float()), _c(beta.detach().float())
+        y = torch.empty_like(x)
+        stats = torch.empty((R, 2), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mdm_ln_fwd(_p(x), _p(g32), _p(b32), _p(y), _p(stats), R, D, float(eps), _dt(x), _stream()), "mdm_ln_fwd")
+        ctx.save_for_backward(x, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stats = ctx.saved_tensors
+        dy = _c(dy)
+        D = x.shape[-1]
+        R = x.numel() // D
+        g32 = _c(gamma.detach().float())
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(D, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(D, dtype=torch.float32, device=x.device)
+        ws = torch.empty(((R + 63) // 64) * D * 2, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mdm_ln_bwd(_p(dy), _p(x), _p(g32), _p(stats), _p(dx), _p(dgamma), _p(dbeta), _p(ws), R, D, _dt(x), _stream()), "mdm_ln_bwd")
+        return dx, dgamma, dbeta, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# --------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------
+class AttentionFn(torch.autograd.Function):
+    """out = softmax(q k^T / sqrt(d)) v + softmax(q k_c^T / sqrt(d) [masked]) v_c."""
+
+    @staticmethod
+    def forward(ctx, qkv, kvc, mask, heads):
+        _require_gpu(qkv)
+        qkv, kvc = _c(qkv), _c(kvc)
+        B = qkv.shape[0]
+        C = qkv.shape[-1] // 3
+        L = qkv.numel() // (B * 3 * C)
+        S = kvc.shape[1] if kvc is not None else 0
+        d = C // heads
+        m32 = _c(mask.float()) if mask is not None else None
+        keep = torch.is_grad_enabled()
+        out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=qkv.device)
+        lse_s = torch.empty((B, heads, L), dtype=torch.float32, device=qkv.device) if keep else None
+        lse_c = torch.empty((B, heads, L), dtype=torch.float32, device=qkv.device) if (keep and kvc is not None) else None
+        oc = torch.empty_like(out) if (keep and kvc is not None) else None
+        _lib.check(
+            _lib.lib().mdm_attn_fwd(_p(qkv), _p(kvc), _p(m32), _p(out), _p(oc), _p(lse_s), _p(lse_c), B, L, S, heads, d, _dt(qkv), _stream()),
+            "mdm_attn_fwd",
+        )
+        ctx.save_for_backward(qkv, kvc, m32, out, oc, lse_s, lse_c)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, kvc, m32, out, oc, lse_s, lse_c = ctx.saved_tensors
+        dout = _c(dout)
+        B = qkv.shape[0]
+        C = qkv.shape[-1] // 3
+        L = qkv.numel() // (B * 3 * C)
+        S = kvc.shape[1] if kvc is not None else 0
+        heads = ctx.heads
+        d = C // heads
+        dqkv = torch.empty_like(qkv)
+        dkvc = torch.empty_like(kvc) if kvc is not None else None
+        delta_s = torch.empty_like(lse_s)
+        delta_c = torch.empty_like(lse_c) if kvc is not None else None
+        _lib.check(
+            _lib.lib().mdm_attn_bwd(_p(qkv), _p(kvc), _p(m32), _p(out), _p(oc), _p(dout), _p(lse_s), _p(lse_c), _p(delta_s),
+                                    _p(delta_c), _p(dqkv), _p(dkvc), B, L, S, heads, d, _dt(qkv), _stream()),
+            "mdm_attn_bwd",
+        )
+        return dqkv, dkvc, None, None
+
+
+def attention(qkv, kvc, mask, heads):
+    return AttentionFn.apply(qkv, kvc, mask, heads)
+
+
+# --------------------------------------------------------------------------------------
+# streaming helpers
+# --------------------------------------------------------------------------------------
+class ToNHWCFn(torch.autograd.Function):
+    """fp32 NCHW (reference layout) -> compute-dtype NHWC with zero channel padding."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, cpad):
+        _require_gpu(x)
+        x = _c(x.float())
+        N, C, H, W = x.shape
+        y = torch.empty((N, H, W, cpad), dtype=dtype, device=x.device)
+        _lib.check(_lib.lib().mdm_nchw_to_nhwc(_p(x), _p(y), N, C, H, W, cpad, _dt(y), _stream()), "mdm_nchw_to_nhwc")
+        ctx.C = C
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        N, H, W, Cs = dy.shape
+        dx = torch.empty((N, ctx.C, H, W), dtype=torch.float32, device=dy.device)
+        _lib.check(_lib.lib().mdm_nhwc_to_nchw(_p(dy), _p(dx), N, ctx.C, H, W, Cs, _dt(dy), _stream()), "mdm_nhwc_to_nchw")
+        return dx, None, None
+
+
+class FromNHWCFn(torch.autograd.Function):
+    """compute-dtype NHWC (first C channels) -> fp32 NCHW."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        _require_gpu(x)
+        x = _c(x)
+        N, H, W, Cs = x.shape
+        y = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mdm_nhwc_to_nchw(_p(x), _p(y), N, C, H, W, Cs, _dt(x), _stream()), "mdm_nhwc_to_nchw")
+        ctx.Cs, ctx.dtype = Cs, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy.float())
+        N, C, H, W = dy.shape
+        dx = torch.empty((N, H, W, ctx.Cs), dtype=ctx.dtype, device=dy.device)
+        _lib.check(_lib.lib().mdm_nchw_to_nhwc(_p(dy), _p(dx), N, C, H, W, ctx.Cs, _dt(dx), _stream()), "mdm_nchw_to_nhwc")
+        return dx, None
+
+
+def to_nhwc(x_nchw, dtype, cpad=None):
+    epv = 4 if dtype == torch.float32 else 8
+    cpad = _round_up(x_nchw.shape[1], epv) if cpad is None else cpad
+    return ToNHWCFn.apply(x_nchw, dtype, cpad)
+
+
+def from_nhwc(x, C):
+    return FromNHWCFn.apply(x, C)
+
+
+class ConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a)
+        a, b = _c(a), _c(b)
+        C1, C2 = a.shape[-1], b.shape[-1]
+        M = a.numel() // C1
+        out = torch.empty(a.shape[:-1] + (C1 + C2,), dtype=a.dtype, device=a.device)
+        _lib.check(_lib.lib().mdm_concat(_p(a), _p(b), _p(out), M, C1, C2, 0, _dt(a), _stream()), "mdm_concat")
+        ctx.C1, ctx.C2 = C1, C2
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        C1, C2 = ctx.C1, ctx.C2
+        M = dout.numel() // (C1 + C2)
+        da = torch.empty(dout.shape[:-1] + (C1,), dtype=dout.dtype, device=dout.device)
+        db = torch.empty(dout.shape[:-1] + (C2,), dtype=dout.dtype, device=dout.device)
+        _lib.check(_lib.lib().mdm_concat(_p(da), _p(db), _p(dout), M, C1, C2, 1, _dt(dout), _stream()), "mdm_concat")
+        return da, db
+
+
+def concat(a, b):
+    return ConcatFn.apply(a, b)
+
+
+class Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = _c(x)
+        N, H, W, C = x.shape
+        y = torch.empty((N, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().mdm_upsample2x(_p(x), _p(y), N, H, W, C, _dt(x), _stream()), "mdm_upsample2x")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        N, H2, W2, C = dy.shape
+        dx = torch.empty((N, H2 // 2, W2 // 2, C), dtype=dy.dtype, device=dy.device)
+        _lib.check(_lib.lib().mdm_downsum2x(_p(dy), _p(dx), N, H2 // 2, W2 // 2, C, _dt(dy), _stream()), "mdm_downsum2x")
+        return dx
+
+
+def upsample2x(x):
+    return Upsample2xFn.apply(x)
+
+
+def _ew(a, b, op):
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().mdm_elementwise(_p(a), _p(b), _p(out), a.numel(), op, _dt(a), _stream()), "mdm_elementwise")
+    return out
+
+
+class SiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return _ew(x, None, 0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return _ew(x, _c(dy), 1)
+
+
+def silu(x):
+    return SiluFn.apply(x)
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a)
+        return _ew(_c(a), _c(b), 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise _lib.MdmHipError("add: shape/dtype mismatch %s %s vs %s %s" % (a.shape, a.dtype, b.shape, b.dtype))
+    return AddFn.apply(a, b)
+
+
+class CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _require_gpu(x)
+        x = _c(x)
+        ctx.src = x.dtype
+        if x.dtype == dtype:
+            return x.view_as(x)
+        y = torch.empty(x.shape, dtype=dtype, device=x.device)
+        _lib.check(_lib.lib().mdm_cast(_p(x), _p(y), x.numel(), _dt(x), _dt(y), _stream()), "mdm_cast")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy.dtype == ctx.src:
+            return dy, None
+        dy = _c(dy)
+        dx = torch.empty(dy.shape, dtype=ctx.src, device=dy.device)
+        _lib.check(_lib.lib().mdm_cast(_p(dy), _p(dx), dy.numel(), _dt(dy), _dt(dx), _stream()), "mdm_cast")
+        return dx, None
+
+
+def cast(x, dtype):
+    return CastFn.apply(x, dtype)
+
+
+def sincos_embedding(times_f32, freqs_f32, dtype):
+    """[B] x [half] -> [B, 2*half] = (sin | cos); no gradient (unet.py:835-836)."""
+    _require_gpu(times_f32)
+    t = _c(times_f32.detach().float())
+    f = _c(freqs_f32.detach().float().reshape(-1))
+    B, half = t.numel(), f.numel()
+    out = torch.empty((B, 2 * half), dtype=dtype, device=t.device)
+    _lib.check(_lib.lib().mdm_sincos_emb(_p(t), _p(f), _p(out), B, half, _dt(out), _stream()), "mdm_sincos_emb")
+    return out
+
+
+class MaskedMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        _require_gpu(x)
+        x = _c(x)
+        B, S, D = x.shape
+        m32 = _c(mask.float()) if mask is not None else None
+        y = torch.empty((B, D), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().mdm_masked_mean(_p(x), _p(m32), _p(y), B, S, D, _dt(x), _stream()), "mdm_masked_mean")
+        ctx.save_for_backward(m32)
+        ctx.shape = (B, S, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (m32,) = ctx.saved_tensors
+        dy = _c(dy)
+        B, S, D = ctx.shape
+        dx = torch.empty((B, S, D), dtype=dy.dtype, device=dy.device)
+        _lib.check(_lib.lib().mdm_masked_mean_bwd(_p(dy), _p(m32), _p(dx), B, S, D, 0, _dt(dy), _stream()), "mdm_masked_mean_bwd")
+        return dx, None
+
+
+def masked_mean(x, mask):
+    return MaskedMeanFn.apply(x, mask)
