@@ -1,0 +1,317 @@
+"""Per-kernel parity: every libmdm_hip entry point (called through the C ABI via mdm_hip.ops)
+against the plain torch fp32 CPU op it replaces, forward and backward.
+
+Tolerances (max-abs error relative to the largest reference magnitude):
+  fp32 mode : 2e-5   (exact-fp32 MFMA; differences are summation order only)
+  bf16 mode : 3e-2   (bf16 storage of activations/weights, fp32 accumulation)
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 3e-2}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def q(t, dtype):
+    """round a CPU fp32 tensor through the compute dtype so both sides see the same inputs"""
+    return t.to(dtype).float()
+
+
+def nhwc(t_nchw, dtype):
+    return t_nchw.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev())
+
+
+def nchw(t_nhwc):
+    return t_nhwc.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize(
+    "N,H,W,Cin,Cout,ks,stride",
+    [
+        (2, 16, 16, 32, 64, 3, 1),
+        (3, 10, 12, 40, 136, 3, 1),     # ragged M / N / K tiles
+        (2, 16, 16, 64, 64, 3, 2),      # downsample
+        (2, 8, 8, 256, 768, 1, 1),      # qkv-style 1x1
+        (1, 7, 5, 24, 8, 3, 1),         # small N config
+        (2, 32, 32, 32, 32, 3, 1),
+        (2, 12, 12, 136, 264, 3, 1),    # Cin not a multiple of the k-tile
+    ],
+)
+def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = q(torch.randn(N, Cin, H, W, generator=g), dtype).requires_grad_()
+    w = q(torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks), dtype).requires_grad_()
+    b = torch.randn(Cout, generator=g).requires_grad_()
+    y_ref = F.conv2d(x, w, b, stride=stride, padding=(ks - 1) // 2)
+    res = q(torch.randn(y_ref.shape, generator=g), dtype).requires_grad_()
+    y_ref = y_ref + res
+    gy = q(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+
+    xd = nhwc(x.detach(), dtype).requires_grad_()
+    wd = w.detach().to(dev()).requires_grad_()
+    bd = b.detach().to(dev()).requires_grad_()
+    rd = nhwc(res.detach(), dtype).requires_grad_()
+    y = ops.conv(xd, wd, bd, residual=rd, stride=stride)
+    y.backward(nhwc(gy, dtype))
+    tol = TOL[dtype]
+    assert relerr(nchw(y), y_ref) < tol
+    assert relerr(nchw(xd.grad), x.grad) < tol
+    assert relerr(wd.grad, w.grad) < tol
+    assert relerr(bd.grad, b.grad) < tol
+    assert relerr(nchw(rd.grad), res.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_padded_stem_and_head(dtype):
+    """3-channel stem (input padded to a chunk) and 3-channel head (output padded)."""
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(1)
+    x = q(torch.randn(2, 3, 16, 16, generator=g), dtype)
+    w = q(torch.randn(32, 3, 3, 3, generator=g) / 5, dtype).requires_grad_()
+    b = torch.randn(32, generator=g).requires_grad_()
+    y_ref = F.conv2d(x, w, b, padding=1)
+    gy = q(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+    wd, bd = w.detach().to(dev()).requires_grad_(), b.detach().to(dev()).requires_grad_()
+    y = ops.conv(ops.to_nhwc(x.to(dev()), dtype), wd, bd)
+    y.backward(nhwc(gy, dtype))
+    tol = TOL[dtype]
+    assert relerr(nchw(y), y_ref) < tol
+    assert relerr(wd.grad, w.grad) < tol and relerr(bd.grad, b.grad) < tol
+
+    h = q(torch.randn(2, 32, 16, 16, generator=g), dtype).requires_grad_()
+    w2 = q(torch.randn(3, 32, 3, 3, generator=g) / 17, dtype).requires_grad_()
+    b2 = torch.randn(3, generator=g).requires_grad_()
+    o_ref = F.conv2d(h, w2, b2, padding=1)
+    go = torch.randn(o_ref.shape, generator=g)
+    o_ref.backward(go)
+    hd = nhwc(h.detach(), dtype).requires_grad_()
+    w2d, b2d = w2.detach().to(dev()).requires_grad_(), b2.detach().to(dev()).requires_grad_()
+    o = ops.from_nhwc(ops.conv(hd, w2d, b2d), 3)
+    o.backward(go.to(dev()))
+    assert relerr(o.cpu(), o_ref) < tol
+    assert relerr(nchw(hd.grad), h.grad) < tol
+    assert relerr(w2d.grad, w2.grad) < tol and relerr(b2d.grad, b2.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_small_rows(dtype):
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(2)
+    x = q(torch.randn(5, 128, generator=g), dtype).requires_grad_()
+    w = q(torch.randn(72, 128, generator=g) / 11, dtype).requires_grad_()
+    b = torch.randn(72, generator=g).requires_grad_()
+    y_ref = F.linear(x, w, b)
+    gy = q(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+    xd = x.detach().to(dtype).to(dev()).requires_grad_()
+    wd, bd = w.detach().to(dev()).requires_grad_(), b.detach().to(dev()).requires_grad_()
+    y = ops.linear(xd, wd, bd)
+    y.backward(gy.to(dtype).to(dev()))
+    tol = TOL[dtype]
+    assert relerr(y.float().cpu(), y_ref) < tol
+    assert relerr(xd.grad.float().cpu(), x.grad) < tol
+    assert relerr(wd.grad, w.grad) < tol and relerr(bd.grad, b.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ffn(dtype):
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(3)
+    N, H, W, C = 2, 8, 8, 64
+    x = q(torch.randn(N, C, H, W, generator=g), dtype).requires_grad_()
+    r = q(torch.randn(N, C, H, W, generator=g), dtype).requires_grad_()
+    w1 = q(torch.randn(4 * C, C, 1, 1, generator=g) / 8, dtype).requires_grad_()
+    b1 = torch.randn(4 * C, generator=g).requires_grad_()
+    w2 = q(torch.randn(C, 4 * C, 1, 1, generator=g) / 16, dtype).requires_grad_()
+    b2 = torch.randn(C, generator=g).requires_grad_()
+    y_ref = F.conv2d(F.gelu(F.conv2d(x, w1, b1)), w2, b2) + r
+    gy = q(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+    ps = [t.detach().to(dev()).requires_grad_() for t in (w1, b1, w2, b2)]
+    xd, rd = nhwc(x.detach(), dtype).requires_grad_(), nhwc(r.detach(), dtype).requires_grad_()
+    y = ops.ffn(xd, *ps, residual=rd)
+    y.backward(nhwc(gy, dtype))
+    tol = TOL[dtype]
+    assert relerr(nchw(y), y_ref) < tol
+    assert relerr(nchw(xd.grad), x.grad) < tol
+    for a, b_ in zip(ps, (w1, b1, w2, b2)):
+        assert relerr(a.grad, b_.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,HW,C,G,film,silu", [
+    (2, 64, 32, 32, False, True),      # 1 channel / group
+    (3, 100, 192, 32, True, True),     # 6 channels / group: chunks straddle groups
+    (2, 256, 768, 32, True, True),
+    (2, 49, 1280, 32, False, False),
+    (2, 1024, 64, 32, False, True),    # 2 channels / group
+])
+def test_group_norm(dtype, N, HW, C, G, film, silu):
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(4)
+    H = int(math.isqrt(HW)); W = HW // H
+    assert H * W == HW
+    x = q(torch.randn(N, C, H, W, generator=g) * 1.7 + 0.6, dtype).requires_grad_()
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_()
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_()
+    fl = q(0.5 * torch.randn(N, 2 * C, generator=g), dtype).requires_grad_() if film else None
+    y_ref = F.group_norm(x, G, gamma, beta, 1e-5)
+    if film:
+        y_ref = y_ref * (1 + fl[:, :C, None, None]) + fl[:, C:, None, None]
+    if silu:
+        y_ref = F.silu(y_ref)
+    gy = q(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+    xd = nhwc(x.detach(), dtype).requires_grad_()
+    gd, bd = gamma.detach().to(dev()).requires_grad_(), beta.detach().to(dev()).requires_grad_()
+    fd = fl.detach().to(dtype).to(dev()).requires_grad_() if film else None
+    y = ops.group_norm(xd, gd, bd, G, 1e-5, film=fd, silu=silu)
+    y.backward(nhwc(gy, dtype))
+    tol = TOL[dtype]
+    assert relerr(nchw(y), y_ref) < tol
+    assert relerr(nchw(xd.grad), x.grad) < tol
+    assert relerr(gd.grad, gamma.grad) < tol and relerr(bd.grad, beta.grad) < tol
+    if film:
+        assert relerr(fd.grad.float().cpu(), fl.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layer_norm(dtype):
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(5)
+    x = q(torch.randn(3, 9, 2048, generator=g) * 2 + 0.3, dtype).requires_grad_()
+    gamma = (1 + 0.3 * torch.randn(2048, generator=g)).requires_grad_()
+    beta = (0.2 * torch.randn(2048, generator=g)).requires_grad_()
+    y_ref = F.layer_norm(x, (2048,), gamma, beta, 1e-5)
+    gy = q(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+    xd = x.detach().to(dtype).to(dev()).requires_grad_()
+    gd, bd = gamma.detach().to(dev()).requires_grad_(), beta.detach().to(dev()).requires_grad_()
+    y = ops.layer_norm(xd, gd, bd, 1e-5)
+    y.backward(gy.to(dtype).to(dev()))
+    tol = TOL[dtype]
+    assert relerr(y.float().cpu(), y_ref) < tol
+    assert relerr(xd.grad.float().cpu(), x.grad) < tol
+    assert relerr(gd.grad, gamma.grad) < tol and relerr(bd.grad, beta.grad) < tol
+
+
+def _attn_ref(qkv, kvc, mask, heads):
+    """qkv [B, L, 3C], kvc [B, S, 2C]: the reference formulation (models/unet.py:276-307)."""
+    import unet_oracle as O
+
+    B, L, C3 = qkv.shape
+    C = C3 // 3
+    t = qkv.transpose(1, 2)
+    out = O.attention_core(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], heads)
+    if kvc is not None:
+        kt = kvc.transpose(1, 2)
+        out = out + O.attention_core(t[:, :C], kt[:, :C], kt[:, C:], heads, mask)
+    return out.transpose(1, 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,L,S,H,d,masked", [
+    (2, 64, 8, 8, 32, False),
+    (2, 256, 32, 8, 96, False),       # UNet-64 level 2 geometry
+    (1, 1024, 32, 8, 64, True),       # UNet-64 level 1 geometry, masked text
+    (2, 200, 77, 2, 64, True),        # ragged L and S (two key tiles for the text)
+    (2, 128, 0, 4, 32, False),        # no cross attention
+])
+def test_attention(dtype, B, L, S, H, d, masked):
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(6)
+    C = H * d
+    qkv = q(torch.randn(B, L, 3 * C, generator=g) * 1.2, dtype).requires_grad_()
+    kvc = q(torch.randn(B, S, 2 * C, generator=g) * 1.2, dtype).requires_grad_() if S else None
+    mask = None
+    if masked:
+        mask = torch.ones(B, S)
+        mask[0, S // 2:] = 0
+        mask[-1, 1:3] = 0
+    # spike one key against one query so the running max jumps mid-stream (online-softmax rescale path)
+    with torch.no_grad():
+        qkv[0, L // 2, :d] *= 6.0
+        qkv[0, (3 * L) // 4, C:C + d] = qkv[0, L // 2, :d] * 0.5
+    o_ref = _attn_ref(qkv, kvc, mask, H)
+    go = q(torch.randn(o_ref.shape, generator=g), dtype)
+    o_ref.backward(go)
+    qd = qkv.detach().to(dtype).to(dev()).requires_grad_()
+    kd = kvc.detach().to(dtype).to(dev()).requires_grad_() if S else None
+    md = mask.to(dev()) if mask is not None else None
+    o = ops.attention(qd, kd, md, H)
+    o.backward(go.to(dtype).to(dev()))
+    tol = TOL[dtype]
+    assert relerr(o.float().cpu(), o_ref) < tol
+    assert relerr(qd.grad.float().cpu(), qkv.grad) < tol
+    if S:
+        assert relerr(kd.grad.float().cpu(), kvc.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_streaming_helpers(dtype):
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(7)
+    tol = TOL[dtype]
+    a = q(torch.randn(2, 24, 6, 10, generator=g), dtype).requires_grad_()
+    b = q(torch.randn(2, 40, 6, 10, generator=g), dtype).requires_grad_()
+    ref = F.silu(torch.cat([F.interpolate(a, scale_factor=2), F.interpolate(b, scale_factor=2)], 1))
+    gy = q(torch.randn(ref.shape, generator=g), dtype)
+    ref.backward(gy)
+    ad, bd = nhwc(a.detach(), dtype).requires_grad_(), nhwc(b.detach(), dtype).requires_grad_()
+    out = ops.silu(ops.concat(ops.upsample2x(ad), ops.upsample2x(bd)))
+    out.backward(nhwc(gy, dtype))
+    assert relerr(nchw(out), ref) < tol
+    assert relerr(nchw(ad.grad), a.grad) < tol and relerr(nchw(bd.grad), b.grad) < tol
+
+    x = q(torch.randn(3, 7, 64, generator=g), dtype).requires_grad_()
+    m = torch.ones(3, 7); m[1, 4:] = 0
+    ref = (m.unsqueeze(-1) * x).sum(1) / m.sum(1, keepdim=True)
+    gy = q(torch.randn(ref.shape, generator=g), dtype)
+    ref.backward(gy)
+    xd = x.detach().to(dtype).to(dev()).requires_grad_()
+    y = ops.masked_mean(xd, m.to(dev()))
+    y.backward(gy.to(dtype).to(dev()))
+    assert relerr(y.float().cpu(), ref) < tol and relerr(xd.grad.float().cpu(), x.grad) < tol
+
+    t = torch.tensor([0.0, 3.0, 999.0])
+    fr = torch.exp(torch.arange(16, dtype=torch.float) * -(math.log(10000) / 16))
+    e = ops.sincos_embedding(t.to(dev()), fr.to(dev()), dtype)
+    ang = t[:, None] * fr[None]
+    assert relerr(e.float().cpu(), torch.cat([ang.sin(), ang.cos()], 1)) < max(tol, 2e-4)
+    s = ops.add(ad.detach(), ad.detach())
+    assert relerr(nchw(s), 2 * a.detach()) < tol
+    c = ops.cast(xd.detach(), torch.float32)
+    assert c.dtype == torch.float32 and relerr(c.cpu(), x.detach()) < tol
+
+
+def test_fails_loudly_without_gpu_tensor():
+    from mdm_hip import _lib, ops
+
+    with pytest.raises(_lib.MdmHipError):
+        ops.silu(torch.randn(4, 8))
