@@ -56,7 +56,16 @@ def _c(t):
 # --------------------------------------------------------------------------------------
 # packed-weight cache
 # --------------------------------------------------------------------------------------
-_wcache = weakref.WeakKeyDictionary()
+_wcache = {}  # id(param) -> (weakref to the param, {dtype: (version key, packed tensors)})
+
+
+def _cache_slot(weight):
+    k = id(weight)
+    ent = _wcache.get(k)
+    if ent is None or ent[0]() is not weight:
+        ent = (weakref.ref(weight, lambda _r, k=k: _wcache.pop(k, None)), {})
+        _wcache[k] = ent
+    return ent[1]
 
 
 def _round_up(v, m):
@@ -67,9 +76,9 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
     """(w_fwd, w_dgrad, bias_padded, Cin_pad, Cout_pad) for a reference-layout weight
     ``(Cout, Cin, k, k)`` or ``(Cout, Cin)``; refreshed when the parameter version changes."""
     key = dtype
-    ent = _wcache.get(weight)
+    ent = _cache_slot(weight)
     ver = (weight._version, None if bias is None else bias._version, weight.data_ptr())
-    if ent is not None and key in ent and ent[key][0] == ver:
+    if key in ent and ent[key][0] == ver:
         return ent[key][1]
     _require_gpu(weight)
     L = _lib.lib()
@@ -95,9 +104,6 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
             bp = torch.cat([bp, bp.new_zeros(cout_pad - cout)])
         bp = _c(bp)
     val = (wf, wd, bp, cin_pad, cout_pad)
-    if ent is None:
-        ent = {}
-        _wcache[weight] = ent
     ent[key] = (ver, val)
     return val
 
@@ -213,13 +219,12 @@ class FFNFn(torch.autograd.Function):
     """y = W2 gelu(W1 x + b1) + b2 + residual  (1x1 convs; unet.py:266-272, 311-312)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual):
+    def forward(ctx, x, w1, b1, w2, b2, residual, keep):
         _require_gpu(x)
         x, residual = _c(x), _c(residual)
         wf1, _, bp1, c_in, c_hid = packed_weight(w1, b1, x.dtype)
         wf2, _, bp2, _, c_out = packed_weight(w2, b2, x.dtype)
         N, H, W, _, _ = _geom(x, 1, 1)
-        keep = torch.is_grad_enabled()
         pre = torch.empty(_out_shape(x, H, W, c_hid), dtype=x.dtype, device=x.device) if keep else None
         a = torch.empty(_out_shape(x, H, W, c_hid), dtype=x.dtype, device=x.device)
         _conv_launch(x, wf1, bp1, None, None, a, pre, N, H, W, c_in, H, W, c_hid, 1, 1, 0, 1)
@@ -248,11 +253,12 @@ class FFNFn(torch.autograd.Function):
         dw1 = _wgrad_launch(x, dpre, N, H, W, c_in, H, W, c_hid, 1, 1).view(w1.shape)
         db1 = _colsum_launch(dpre, M, c_hid)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[5]) else None
-        return dx, dw1, db1, dw2, db2, dres
+        return dx, dw1, db1, dw2, db2, dres, None
 
 
 def ffn(x, w1, b1, w2, b2, residual):
-    return FFNFn.apply(x, w1, b1, w2, b2, residual)
+    # autograd.Function.forward runs with grad mode off, so the "will there be a backward" decision is taken here
+    return FFNFn.apply(x, w1, b1, w2, b2, residual, torch.is_grad_enabled())
 
 
 # --------------------------------------------------------------------------------------
@@ -351,7 +357,7 @@ class AttentionFn(torch.autograd.Function):
     """out = softmax(q k^T / sqrt(d)) v + softmax(q k_c^T / sqrt(d) [masked]) v_c."""
 
     @staticmethod
-    def forward(ctx, qkv, kvc, mask, heads):
+    def forward(ctx, qkv, kvc, mask, heads, keep):
         _require_gpu(qkv)
         qkv, kvc = _c(qkv), _c(kvc)
         B = qkv.shape[0]
@@ -360,7 +366,6 @@ class AttentionFn(torch.autograd.Function):
         S = kvc.shape[1] if kvc is not None else 0
         d = C // heads
         m32 = _c(mask.float()) if mask is not None else None
-        keep = torch.is_grad_enabled()
         out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=qkv.device)
         lse_s = torch.empty((B, heads, L), dtype=torch.float32, device=qkv.device) if keep else None
         lse_c = torch.empty((B, heads, L), dtype=torch.float32, device=qkv.device) if (keep and kvc is not None) else None
@@ -392,11 +397,11 @@ class AttentionFn(torch.autograd.Function):
                                     _p(delta_c), _p(dqkv), _p(dkvc), B, L, S, heads, d, _dt(qkv), _stream()),
             "mdm_attn_bwd",
         )
-        return dqkv, dkvc, None, None
+        return dqkv, dkvc, None, None, None
 
 
 def attention(qkv, kvc, mask, heads):
-    return AttentionFn.apply(qkv, kvc, mask, heads)
+    return AttentionFn.apply(qkv, kvc, mask, heads, torch.is_grad_enabled())
 
 
 # --------------------------------------------------------------------------------------

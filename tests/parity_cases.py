@@ -88,3 +88,16 @@ def oracle_run(name, dtype=torch.float32, with_grad=True):
         loss_of(outs, inp["gys"]).backward()
         grads = {k: v.grad for k, v in leaf.items()}
     return [o.detach() for o in as_list(outs)], grads
+
+
+def grad_errors(grads, g_ref, floor_frac=1e-2):
+    """per-parameter ||g - g_ref|| / max(||g_ref||, floor).  Gradients that are mathematically zero (e.g. the
+    bias of a conv feeding a 1-channel-per-group GroupNorm) are rounding noise on both sides, so every tensor
+    is measured against a floor of ``floor_frac`` x the median gradient norm rather than its own noise norm."""
+    norms = sorted(float(g.double().norm()) for g in g_ref.values())
+    floor = floor_frac * norms[len(norms) // 2]
+    errs = {}
+    for k, r in g_ref.items():
+        d = float((grads[k].detach().double().cpu() - r.double()).norm())
+        errs[k] = d / max(float(r.double().norm()), floor)
+    return errs, floor
