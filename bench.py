@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoise train steps/s of the cc12m_64x64 U-Net (bf16, batch 64 per GPU).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one synthetic batch: Diffusion.get_loss (noising +
+U-Net forward) -> backward -> gradient all-reduce (N > 1) -> clip -> AdamW -> EMA, i.e. the
+reference's ``trainer.train_batch`` (trainer.py:13-96).  Inputs are resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line (contract in the task statement) with two extra
+objects: ``roofline`` (dominant kernel, measured live with HIP events on the launch stream)
+and ``cpu_baseline`` (the CPU oracle timed on this box's host cores, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "ml-mdm_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic forward matmul-class FLOPs per sample, measured on the reference (SURVEY.md section 8a/8d, S = 32)
+FWD_GFLOP_PER_SAMPLE = {"unet64": 363.9, "nested256": 589.1}
+PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_F32_TFLOPS = 157.3
+
+
+def build(workload, device, seed=0):
+    import unet_oracle as O
+    import mdm_hip
+    from mdm_hip import configs, diffusion, samplers
+
+    sc = samplers.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
+                                loss_target_type="DDPM", threshold_function="CLIP")
+    torch.manual_seed(seed)
+    if workload == "unet64":
+        net = mdm_hip.UNet(3, 3, configs.unet64_config(2048))
+        pipe_cls, dcfg, side = diffusion.Diffusion, diffusion.DiffusionConfig(sampler_config=sc, use_vdm_loss_weights=False), 64
+    else:
+        sc.schedule_shifted, sc.rescale_signal = True, 1
+        net = mdm_hip.NestedUNet(3, 3, configs.nested256_config(2048))
+        dcfg = diffusion.NestedDiffusionConfig(sampler_config=sc, use_vdm_loss_weights=False, use_double_loss=True, no_use_residual=True)
+        pipe_cls, side = diffusion.NestedDiffusion, 256
+    # the reference zero-initialises ~40% of the tensors; randomise them (seeded) so no work is degenerate
+    net.load_state_dict(O.randomize_zero_params(net.state_dict(), seed=4321))
+    pipe = pipe_cls(net, dcfg).to(device)
+    return pipe, side
+
+
+def synthetic_batch(batch, side, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {
+        "images": (torch.rand(batch, 3, side, side, generator=g) * 2 - 1).to(device),
+        "lm_outputs": torch.randn(batch, 32, 2048, generator=g).to(device),
+        "lm_mask": torch.ones(batch, 32).to(device),
+    }
+
+
+def cpu_baseline(workload, batch_ref):
+    """the oracle (CPU restatement of the reference path) fwd+bwd on the host cores; bounded sample"""
+    import unet_oracle as O
+    import mdm_hip
+    from mdm_hip import configs
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = 2 if workload == "unet64" else 1
+    side = 64 if workload == "unet64" else 256
+    torch.manual_seed(0)
+    cfg = configs.unet64_config(2048) if workload == "unet64" else configs.nested256_config(2048)
+    cls = mdm_hip.UNet if workload == "unet64" else mdm_hip.NestedUNet
+    sd = O.randomize_zero_params(cls(3, 3, cfg).state_dict(), seed=4321)
+    leaf = {k: v.requires_grad_(True) for k, v in sd.items()}
+    cfg = configs.unet64_config(2048) if workload == "unet64" else configs.nested256_config(2048)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b, 3, side, side, generator=g)
+    if workload != "unet64":
+        x = [x, torch.randn(b, 3, 64, 64, generator=g)]
+    cond, mask = torch.randn(b, 32, 2048, generator=g), torch.ones(b, 32)
+    t0 = time.perf_counter()
+    out = O.model_forward(leaf, cfg, x, torch.randint(0, 1000, (b,), generator=g), cond, mask)
+    loss = sum(o.square().mean() for o in (out if isinstance(out, list) else [out]))
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {
+        "value": round((b / batch_ref) / dt, 6),
+        "unit": "denoise-steps/s (batch %d equivalent)" % batch_ref,
+        "cores": cores,
+        "kind": "port",
+        "sample": "1 un-warmed fwd+bwd of the fp32 CPU oracle at batch %d (%.1f s), scaled by %d/%d" % (b, dt, b, batch_ref),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="unet64", choices=["unet64", "nested256"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 / 16)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from mdm_hip import distributed as mdist
+    from mdm_hip import ops
+    from mdm_hip.trainer import TrainStep
+
+    local, rank, world = mdist.init_distributed_singlenode()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    batch = args.batch or (64 if args.workload == "unet64" else 16)
+
+    pipe, side = build(args.workload, device)
+    step = TrainStep(pipe, bf16=args.dtype == "bf16")
+    sample = synthetic_batch(batch, side, device, seed=1234 + rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(sample)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(sample)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        # one extra, untimed step with HIP events around every GEMM-class launch (on the launch stream)
+        ops.profile_begin()
+        step(sample)
+        torch.cuda.synchronize()
+        roof = ops.profile_end(PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        steps_per_s = world * args.steps / dt
+        alg_tflop_step = 3 * FWD_GFLOP_PER_SAMPLE[args.workload] * batch / 1e3
+        out = {
+            "metric": "denoise-steps/sec (train fwd+bwd+optimizer, %s, batch %d per GPU)" % (
+                "cc12m_64x64 U-Net" if args.workload == "unet64" else "cc12m_256x256 NestedUNet", batch),
+            "value": round(steps_per_s, 4),
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (U(-1,1) images, N(0,1) text states [B,32,2048], random-init weights with zero-init tensors randomised)",
+            "config": {
+                "workload": "%s train step, per-GPU batch %d, global batch %d" % (args.workload, batch, batch * world),
+                "global_batch": batch * world,
+                "parallelism": "dp%d" % world,
+                "samples_per_s": round(steps_per_s * batch, 2),
+                "step_algorithmic_tflop": round(alg_tflop_step, 2),
+                "step_mfma_roofline_frac": round(alg_tflop_step / (ms / 1e3) / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4),
+            },
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,167 @@
+"""One process per GPU data parallelism over RCCL (``backend="nccl"`` on ROCm) -- the only
+parallelism the reference has (clis/train_parallel.py:147-154, distributed.py:27-61).
+
+``init_distributed_singlenode`` keeps the reference's entry point.  ``GradReducer`` replaces
+torch DDP's reducer with a design sized for 8 x MI355X on point-to-point xGMI links:
+
+  * the gradients of all parameters live in ONE flat fp32 arena; ``p.grad`` are views into it,
+    so there is no bucket copy-in/copy-out and the optimizer tail can stream the arena;
+  * the arena is cut into a few LARGE buckets (default 256 MiB, not DDP's 25 MiB): on xGMI a
+    collective is per-link bound (7 links x ~153 GB/s per GPU), so fewer, larger all-reduces
+    keep every link busy and amortise launch latency; buckets are ordered by the order in which
+    backward produces gradients (reverse registration), so the first all-reduce starts while
+    most of backward is still running;
+  * a bucket's all-reduce is issued from a post-accumulate-grad hook as soon as its last
+    gradient is ready, asynchronously on RCCL's own stream; ``finish()`` joins before the
+    optimizer.  Optional bf16 wire format halves the bytes.
+"""
+import os
+from datetime import timedelta
+
+import torch
+import torch.distributed as dist
+
+
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_local_rank() -> int:
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def print0(*a, **k):
+    if get_rank() == 0:
+        print(*a, **k)
+
+
+def init_distributed_singlenode(timeout: int = 0, backend: str = None):
+    """env:// rendezvous, one rank per GPU (reference distributed.py:27-61).  Returns
+    (local_rank, global_rank, world_size); a no-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 or "MASTER_ADDR" not in os.environ:
+        return 0, 0, 1
+    rank, local = int(os.environ["RANK"]), get_local_rank()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {"timeout": timedelta(seconds=timeout)} if timeout else {}
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        kw["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank, **kw)
+    dist.barrier()
+    return local, rank, world
+
+
+class GradReducer:
+    def __init__(self, params, bucket_mb: float = 256.0, wire_dtype: torch.dtype = None, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.wire_dtype = wire_dtype
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        # arena order = reverse registration order ~ the order backward produces gradients
+        order = list(reversed(self.params))
+        cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets = []          # (start, end)
+        self._bucket_of = {}
+        off = b_start = 0
+        for p in order:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self._bucket_of[p] = len(self.buckets)
+            off += n
+            if off - b_start >= cap:
+                self.buckets.append((b_start, off))
+                b_start = off
+        if off > b_start:
+            self.buckets.append((b_start, off))
+        self._need = [0] * len(self.buckets)
+        for p in order:
+            self._need[self._bucket_of[p]] += 1
+        self._pending = list(self._need)
+        self._work = []
+        self._enabled = True
+        if self.world > 1:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    # -- called by autograd, once per parameter per backward
+    def _hook(self, p):
+        if not self._enabled:
+            return
+        b = self._bucket_of[p]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        buf = self.flat[s:e]
+        if self.wire_dtype is not None and self.wire_dtype != torch.float32:
+            wire = buf.to(self.wire_dtype)
+            wire.div_(self.world)
+            h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work.append((h, buf, wire))
+        else:
+            buf.div_(self.world)  # pre-scale: SUM of pre-divided == AVG, and gloo has no AVG
+            h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work.append((h, None, None))
+
+    def no_sync(self):
+        """context manager for gradient-accumulation micro-steps (train_parallel.py:201-203)"""
+        reducer = self
+
+        class _Ctx:
+            def __enter__(self):
+                reducer._enabled = False
+
+            def __exit__(self, *a):
+                reducer._enabled = True
+
+        return _Ctx()
+
+    def finish(self):
+        """join the outstanding all-reduces; afterwards every p.grad holds the rank-average"""
+        if self.world > 1 and self._enabled:
+            missing = [b for b, n in enumerate(self._pending) if n != 0]
+            if missing:
+                raise RuntimeError("buckets %s did not receive all their gradients (unused parameters?)" % missing)
+            for h, buf, wire in self._work:
+                h.wait()
+                if wire is not None:
+                    buf.copy_(wire)
+            self._work = []
+            self._pending = list(self._need)
+
+    def zero_grad(self):
+        self.flat.zero_()
+
+    def broadcast_parameters(self, src: int = 0):
+        """rank-0 parameters to everyone, as one flat message per 256 MiB (DDP does this at wrap time)"""
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            chunk, acc = [], 0
+            for p in self.params:
+                chunk.append(p)
+                acc += p.numel()
+                if acc * 4 >= (256 << 20):
+                    self._bcast(chunk, src)
+                    chunk, acc = [], 0
+            if chunk:
+                self._bcast(chunk, src)
+
+    def _bcast(self, ps, src):
+        flat = torch.cat([p.detach().reshape(-1) for p in ps])
+        dist.broadcast(flat, src, group=self.group)
+        off = 0
+        for p in ps:
+            p.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()

@@ -109,14 +109,72 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
 
 
 # --------------------------------------------------------------------------------------
+# optional per-launch timing of the GEMM-class kernels (bench.py roofline leg)
+# --------------------------------------------------------------------------------------
+_prof = None
+
+
+def profile_begin():
+    """Start recording HIP events (on the launch stream = torch's current stream) around every
+    conv / wgrad launch, together with the algorithmic FLOPs of the launch."""
+    global _prof
+    _prof = []
+
+
+def _prof_wrap(name, flops, fn):
+    if _prof is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    _prof.append((name, flops, e0, e1))
+    return r
+
+
+def profile_end(peak_tflops):
+    """-> the ``roofline`` object of bench.py for the kernel with the largest total time."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    agg = {}
+    for name, flops, e0, e1 in rec:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += e0.elapsed_time(e1) * 1e-3
+    if not agg:
+        return None
+    table = {k: {"launches": v[0], "alg_tflop": round(v[1] / 1e12, 3), "time_ms": round(v[2] * 1e3, 3),
+                 "tflops": round(v[1] / v[2] / 1e12, 1)} for k, v in agg.items()}
+    dom = max(agg, key=lambda k: agg[k][2])
+    n, fl, t = agg[dom]
+    ach = fl / t / 1e12
+    return {
+        "bound": "mfma", "achieved": round(ach, 1), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(ach / peak_tflops, 4),
+        "traffic": None, "kernel": dom, "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4),
+        "alg_gflop_per_launch": round(fl / n / 1e9, 2), "all_gemm_kernels": table,
+    }
+
+
+# --------------------------------------------------------------------------------------
 # raw launches
 # --------------------------------------------------------------------------------------
 def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, stride, transposed, act):
-    _lib.check(
-        _lib.lib().mdm_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(aux), _p(y), _p(ypre), N, H, W, Cin, Ho, Wo, Cout,
-                                ks, stride, transposed, act, _dt(x), _stream()),
-        "mdm_conv_fwd",
-    )
+    def go():
+        _lib.check(
+            _lib.lib().mdm_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(aux), _p(y), _p(ypre), N, H, W, Cin, Ho, Wo, Cout,
+                                    ks, stride, transposed, act, _dt(x), _stream()),
+            "mdm_conv_fwd",
+        )
+
+    if _prof is None:
+        return go()
+    tile = 32 if Cout <= 32 else (64 if Cout <= 64 else 128)
+    mode = "1x1" if ks == 1 else ("3x3_T2" if transposed else "3x3")
+    name = "conv_gemm_kernel<%s,128x%d,%s>" % ("f32" if x.dtype == torch.float32 else "bf16", tile, mode)
+    flops = 2.0 * N * Ho * Wo * Cout * ks * ks * Cin / (4 if transposed else 1)
+    return _prof_wrap(name, flops, go)
 
 
 def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride):
@@ -127,8 +185,16 @@ def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride):
     _lib.check(L.mdm_conv_wgrad_plan(M, Cout, K, _dt(x), ctypes.byref(splits), ctypes.byref(wsb)), "mdm_conv_wgrad_plan")
     ws = _f32_ws(wsb.value, x.device)
     dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device)
-    _lib.check(L.mdm_conv_wgrad(_p(x), _p(dy), _p(dw), _p(ws), N, H, W, Cin, Ho, Wo, Cout, ks, stride, _dt(x), _stream()),
-               "mdm_conv_wgrad")
+
+    def go():
+        _lib.check(L.mdm_conv_wgrad(_p(x), _p(dy), _p(dw), _p(ws), N, H, W, Cin, Ho, Wo, Cout, ks, stride, _dt(x), _stream()),
+                   "mdm_conv_wgrad")
+
+    if _prof is None:
+        go()
+    else:
+        name = "conv_wgrad_kernel<%s,%s>+reduce" % ("f32" if x.dtype == torch.float32 else "bf16", "1x1" if ks == 1 else "3x3")
+        _prof_wrap(name, 2.0 * M * Cout * K, go)
     return dw
 
 
