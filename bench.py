@@ -70,7 +70,9 @@ def cpu_baseline(workload, batch_ref):
     import mdm_hip
     from mdm_hip import configs
 
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool degrades badly beyond a few dozen threads on this op mix (632 s at 256 threads
+    # vs ~10 s at 8 for the same work), so the baseline uses at most 32 host threads and reports that count
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     b = 2 if workload == "unet64" else 1
     side = 64 if workload == "unet64" else 256

@@ -81,8 +81,9 @@ __device__ __forceinline__ void load_nat_tile(char* dst, const T* src, int rs, i
   using G = AttnGeom<T, D>;
   for (int c = tid; c < 64 * G::CPR; c += 256) {
     const int row = c / G::CPR, cc = c - row * G::CPR;
-    uint4 val = {0u, 0u, 0u, 0u};
-    if (row0 + row < nrows) val = *reinterpret_cast<const uint4*>(src + (size_t)(row0 + row) * rs + cc * G::EPV);
+    const bool ok = row0 + row < nrows;
+    uint4 val = *reinterpret_cast<const uint4*>(src + (ok ? (size_t)(row0 + row) * rs + cc * G::EPV : (size_t)0));
+    val.x = ok ? val.x : 0u; val.y = ok ? val.y : 0u; val.z = ok ? val.z : 0u; val.w = ok ? val.w : 0u;
     *reinterpret_cast<uint4*>(dst + (cc >> 3) * (64 * 128) + lds_chunk_off(row, cc & 7)) = val;
   }
 }
@@ -92,13 +93,15 @@ __device__ __forceinline__ void load_tr_tile(char* dst, const T* src, int rs, in
   using G = AttnGeom<T, D>;
   constexpr int NBLK = (64 / G::EPV) * G::CPR;
   for (int bi = tid; bi < NBLK; bi += 256) {
-    const int kb = bi / G::CPR, cc = bi - kb * G::CPR;
+    // 8 consecutive lanes = the row blocks of one channel chunk: conflict-free transposed stores (see wgrad)
+    constexpr int KB = 64 / G::EPV;
+    const int cc = bi / KB, kb = bi - cc * KB;
     Blk<T> blk;
 #pragma unroll
     for (int e = 0; e < G::EPV; ++e) {
       const int row = row0 + kb * G::EPV + e;
-      if (row < nrows) blk.load_row(e, src + (size_t)row * rs + cc * G::EPV);
-      else blk.zero_row(e);
+      const bool ok = row < nrows;
+      blk.load_row_sel(e, src + (ok ? (size_t)row * rs + cc * G::EPV : (size_t)0), ok);
     }
 #pragma unroll
     for (int c = 0; c < G::EPV; ++c)
@@ -268,24 +271,42 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 // backward pre-pass: delta_self = rowsum(dO * (O - O_cross)), delta_cross = rowsum(dO * O_cross)
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ void attn_delta_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ oc,
-                                  float* __restrict__ dself, float* __restrict__ dcross, int B, int H, int L, int d,
-                                  size_t o_bs, int o_rs) {
-  const size_t total = (size_t)B * H * L;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int qi = (int)(i % L);
-    const size_t bh = i / L;
-    const int h = (int)(bh % H), b = (int)(bh / H);
-    const size_t off = (size_t)b * o_bs + (size_t)qi * o_rs + (size_t)h * d;
-    float a = 0.f, c = 0.f;
-    for (int j = 0; j < d; ++j) {
-      const float g = to_f32(dout[off + j]);
-      const float ov = to_f32(out[off + j]);
-      const float cv = oc ? to_f32(oc[off + j]) : 0.f;
-      a += g * (ov - cv); c += g * cv;
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                         const T* __restrict__ oc, float* __restrict__ dself,
+                                                         float* __restrict__ dcross, int B, int H, int L, int d,
+                                                         size_t rows) {
+  // one thread per 16-byte chunk of a (b, i) row of C = H*d channels; partial dot products are combined per head
+  constexpr int EPV = Tr<T>::EPV;
+  __shared__ float pa[256], pc[256];
+  const int C = H * d, cpr = C / EPV, cph = d / EPV;
+  const int rpb = 256 / cpr > 0 ? 256 / cpr : 1;           // rows per block (cpr <= 256 checked on the host)
+  const int tid = threadIdx.x;
+  const int lr = tid / cpr, cc = tid - lr * cpr;
+  const size_t row = (size_t)blockIdx.x * rpb + lr;
+  float a = 0.f, c = 0.f;
+  if (lr < rpb && row < rows) {
+    const size_t off = row * C + (size_t)cc * EPV;
+    Chunk<T> g, o, x;
+    g.load(dout + off);
+    o.load(out + off);
+    if (oc) x.load(oc + off);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float cv = oc ? x.v[e] : 0.f;
+      a += g.v[e] * (o.v[e] - cv);
+      c += g.v[e] * cv;
     }
-    dself[i] = a;
-    if (dcross) dcross[i] = c;
+  }
+  pa[tid] = a; pc[tid] = c;
+  __syncthreads();
+  if (lr < rpb && row < rows && cc % cph == 0) {
+    float sa = 0.f, sc = 0.f;
+    for (int j = 0; j < cph; ++j) { sa += pa[tid + j]; sc += pc[tid + j]; }
+    const int h = cc / cph;
+    const size_t b = row / L, i = row - b * L;
+    const size_t o = (b * H + h) * L + i;
+    dself[o] = sa;
+    if (dcross) dcross[o] = sc;
   }
 }
 
@@ -617,12 +638,18 @@ extern "C" int mdm_attn_bwd(const void* qkv, const void* kvc, const float* mask,
   a.dk_bs = a.q_bs; a.dk_rs = 3 * C;
   a.B = B; a.H = H; a.L = L; a.S = S; a.scale = 1.0f / sqrtf((float)d);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const size_t total = (size_t)B * H * L;
-  const int nb = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-  if (dtype == DT_F32)
-    hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)(kvc ? out_cross : nullptr), delta_self, kvc ? delta_cross : nullptr, B, H, L, d, a.o_bs, a.o_rs);
-  else
-    hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)dout, (const bf16*)out, (const bf16*)(kvc ? out_cross : nullptr), delta_self, kvc ? delta_cross : nullptr, B, H, L, d, a.o_bs, a.o_rs);
+  {
+    const int epv = dtype == DT_F32 ? 4 : 8;
+    const int cpr = C / epv;
+    MDM_CHECK_ARG(cpr <= 256);
+    const int rpb = 256 / cpr;
+    const size_t rows = (size_t)B * L;
+    const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
+    if (dtype == DT_F32)
+      hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)(kvc ? out_cross : nullptr), delta_self, kvc ? delta_cross : nullptr, B, H, L, d, rows);
+    else
+      hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)dout, (const bf16*)out, (const bf16*)(kvc ? out_cross : nullptr), delta_self, kvc ? delta_cross : nullptr, B, H, L, d, rows);
+  }
   void* dkc = dkvc;
   void* dvc = kvc ? (char*)dkvc + (size_t)C * es : nullptr;
 #define MDM_ATTN_BWD(DD)                                                                                    \

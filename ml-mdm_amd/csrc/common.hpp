@@ -129,6 +129,11 @@ template <> struct Blk<float> {
   f32x4 r[4];
   __device__ __forceinline__ void zero_row(int i) { r[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   __device__ __forceinline__ void load_row(int i, const float* p) { r[i] = *reinterpret_cast<const f32x4*>(p); }
+  // branch-free guarded load: `p` must be a mapped address even when !valid
+  __device__ __forceinline__ void load_row_sel(int i, const float* p, bool valid) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    r[i] = f32x4{valid ? t[0] : 0.f, valid ? t[1] : 0.f, valid ? t[2] : 0.f, valid ? t[3] : 0.f};
+  }
   // row c of the transposed block: elements (r[0][c], r[1][c], r[2][c], r[3][c])
   __device__ __forceinline__ uint4 col(int c) const {
     f32x4 o = {r[0][c], r[1][c], r[2][c], r[3][c]};
@@ -139,6 +144,10 @@ template <> struct Blk<bf16> {
   uint4 r[8];
   __device__ __forceinline__ void zero_row(int i) { r[i] = uint4{0u, 0u, 0u, 0u}; }
   __device__ __forceinline__ void load_row(int i, const bf16* p) { r[i] = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void load_row_sel(int i, const bf16* p, bool valid) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    r[i] = uint4{valid ? t.x : 0u, valid ? t.y : 0u, valid ? t.z : 0u, valid ? t.w : 0u};
+  }
   __device__ __forceinline__ uint32_t word(const uint4& v, int i) const {
     return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
   }

@@ -39,6 +39,9 @@ struct ConvArgs {
 
 enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };
 
+// 16-byte-aligned zeros in device memory: the source of every out-of-range LDS-DMA chunk
+__device__ __attribute__((aligned(16))) uint4 g_zero_page[4] = {};
+
 template <typename T, int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   constexpr int EPV = Tr<T>::EPV, BK = Tr<T>::BK, KSTEPS = Tr<T>::KSTEPS;
@@ -61,8 +64,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   const T* __restrict__ Wp = reinterpret_cast<const T*>(p.w);
 
   // ---- loader state -------------------------------------------------------
-  const int lrow = tid >> 3, lchunk = tid & 7;
-  const int pchunk = lchunk ^ (lrow & 7);
+  const int lrow = tid >> 3;
+  const int lchunk = (tid & 7) ^ (lrow & 7);   // logical chunk this thread fetches (physical slot = tid & 7)
   int a_pix[AJ];   // n * H * W  (pixel index base of the image), -1 if row >= M
   int a_oh[AJ], a_ow[AJ];
 #pragma unroll
@@ -85,53 +88,49 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   int tap = 0, cin = kcur;
   if (MODE != MODE_1x1) { tap = kcur / p.Cin; cin = kcur - tap * p.Cin; }
 
-  uint4 ra[AJ], rb[BJ];
-  auto load_tile = [&]() {
-    const bool kvalid = kcur < p.K;
-    int kh = 0, kw = 0;
-    if (MODE != MODE_1x1) { kh = (tap * 11) >> 5; kw = tap - 3 * kh; }
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      bool v = kvalid && a_pix[j] >= 0;
-      size_t off;
-      if (MODE == MODE_1x1) {
-        off = (size_t)a_pix[j] * p.Cin + kcur;
-      } else if (MODE == MODE_3x3) {
-        const int ih = a_oh[j] * p.stride + kh - 1, iw = a_ow[j] * p.stride + kw - 1;
-        v = v && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-        off = (size_t)(a_pix[j] + ih * p.W + iw) * p.Cin + cin;
-      } else {  // transposed stride 2: source index = (o + tap - 1) / 2 when even
-        const int th = a_oh[j] + kh - 1, tw = a_ow[j] + kw - 1;
-        const int ih = th >> 1, iw = tw >> 1;
-        v = v && th >= 0 && tw >= 0 && !(th & 1) && !(tw & 1) && ih < p.H && iw < p.W;
-        off = (size_t)(a_pix[j] + ih * p.W + iw) * p.Cin + cin;
-      }
-      uint4 z = {0u, 0u, 0u, 0u};
-      ra[j] = v ? *reinterpret_cast<const uint4*>(X + off) : z;
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-      const int n = n0 + lrow + 32 * j;
-      const bool v = kvalid && n < p.Cout;
-      uint4 z = {0u, 0u, 0u, 0u};
-      rb[j] = v ? *reinterpret_cast<const uint4*>(Wp + (size_t)n * p.K + kcur) : z;
-    }
-  };
-  auto advance_k = [&]() {
-    kcur += BK;
-    if (MODE != MODE_1x1) {
-      cin += BK;
-      while (cin >= p.Cin) { cin -= p.Cin; ++tap; }
-    }
-  };
-  auto store_tile = [&](char* stage) {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j)
-      *reinterpret_cast<uint4*>(stage + (lrow + 32 * j) * 128 + pchunk * 16) = ra[j];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j)
-      *reinterpret_cast<uint4*>(stage + A_BYTES + (lrow + 32 * j) * 128 + pchunk * 16) = rb[j];
-  };
+  // Global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  The DMA writes
+  // lane-linear (wave base + lane * 16), i.e. thread (row = tid >> 3, slot = tid & 7) of pass j fills physical
+  // slot `slot` of row `row + 32 j`; the XOR swizzle therefore moves to the SOURCE side: the thread fetches the
+  // logical chunk lchunk = slot ^ (row & 7).  Out-of-range taps / rows / k read a 16-byte zero page.
+  const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
+#define MDM_GLDS(src, lds_off)                                                                            \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                  \
+                                   (__attribute__((address_space(3))) void*)(lds_off), 16, 0, 0)
+#define MDM_STAGE_TILE(stage)                                                                             \
+  {                                                                                                       \
+    const bool kvalid = kcur < p.K;                                                                       \
+    int kh = 0, kw = 0;                                                                                   \
+    if (MODE != MODE_1x1) { kh = (tap * 11) >> 5; kw = tap - 3 * kh; }                                    \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                      \
+      bool v = kvalid && a_pix[j] >= 0;                                                                   \
+      size_t off;                                                                                         \
+      if (MODE == MODE_1x1) {                                                                             \
+        off = (size_t)a_pix[j] * p.Cin + kcur;                                                            \
+      } else if (MODE == MODE_3x3) {                                                                      \
+        const int ih = a_oh[j] * p.stride + kh - 1, iw = a_ow[j] * p.stride + kw - 1;                     \
+        v = v && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);                        \
+        off = (size_t)(a_pix[j] + ih * p.W + iw) * p.Cin + cin;                                           \
+      } else {                                                                                            \
+        const int th = a_oh[j] + kh - 1, tw = a_ow[j] + kw - 1;                                           \
+        const int ih = th >> 1, iw = tw >> 1;                                                             \
+        v = v && th >= 0 && tw >= 0 && !(th & 1) && !(tw & 1) && ih < p.H && iw < p.W;                    \
+        off = (size_t)(a_pix[j] + ih * p.W + iw) * p.Cin + cin;                                           \
+      }                                                                                                   \
+      const T* src = v ? X + off : reinterpret_cast<const T*>(g_zero_page);                               \
+      MDM_GLDS(src, (stage) + j * 4096 + wave_lds);                                                       \
+    }                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                                      \
+      const int n = n0 + lrow + 32 * j;                                                                   \
+      const bool v = kvalid && n < p.Cout;                                                                \
+      const T* src = v ? Wp + (size_t)n * p.K + kcur : reinterpret_cast<const T*>(g_zero_page);           \
+      MDM_GLDS(src, (stage) + A_BYTES + j * 4096 + wave_lds);                                             \
+    }                                                                                                     \
+    kcur += BK;                                                                                           \
+    if (MODE != MODE_1x1) {                                                                               \
+      cin += BK;                                                                                          \
+      while (cin >= p.Cin) { cin -= p.Cin; ++tap; }                                                       \
+    }                                                                                                     \
+  }
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -140,14 +139,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = (p.K + BK - 1) / BK;
-  load_tile();
-  advance_k();
-  store_tile(smem);
+  MDM_STAGE_TILE(smem);
   __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
     char* cur = smem + (kt & 1) * STAGE;
     const bool more = kt + 1 < ntiles;
-    if (more) { load_tile(); advance_k(); }
+    if (more) MDM_STAGE_TILE(smem + ((kt + 1) & 1) * STAGE);
     const char* As = cur;
     const char* Bs = cur + A_BYTES;
 #pragma unroll
@@ -162,9 +159,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
     }
-    if (more) store_tile(smem + ((kt + 1) & 1) * STAGE);
-    __syncthreads();
+    __syncthreads();   // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
   }
+#undef MDM_STAGE_TILE
+#undef MDM_GLDS
 
   // ---- epilogue -------------------------------------------------------------
   T* __restrict__ Y = reinterpret_cast<T*>(p.y);
@@ -251,8 +249,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int tiles_k = (p.K + BN - 1) / BN;
   const int tiles_n = (p.Cout + BM - 1) / BM;
   const int tiles = tiles_k * tiles_n;
-  const int split = blockIdx.x / tiles;
-  const int t = blockIdx.x - split * tiles;
+  // XCD-aware order: all output tiles of one m-range (split) run on the same XCD at the same time, so the dY / X
+  // rows they stream in lock-step are fetched from HBM once and then hit that XCD's L2
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lid / tiles;
+  const int t = lid - split * tiles;
   const int n0 = (t / tiles_k) * BM, k0 = (t % tiles_k) * BN;
 
   const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
@@ -267,8 +268,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     const int id = tid + 256 * i;
     b_op[i] = id / BLOCKS;
     const int r = id - b_op[i] * BLOCKS;
-    b_cc[i] = r % CPR;
-    b_mb[i] = r / CPR;
+    // 8 consecutive lanes = the 8 pixel blocks of one channel chunk: their transposed 16-byte stores fill one
+    // whole 128-byte LDS row (conflict-free), and their 8 x (8 channel-chunk lanes) loads cover full 128-byte lines
+    b_mb[i] = r % MB;
+    b_cc[i] = r / MB;
     if (b_op[i] == 0) {
       b_cvalid[i] = (n0 + b_cc[i] * EPV) < p.Cout;
       b_tap[i] = 0; b_cin[i] = 0;
@@ -285,47 +288,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int mt_total = (p.M + BKM - 1) / BKM;
   const int mt_end = min(mt_total, mt_begin + p.mtiles_per_split);
 
-  auto load_tile = [&](int mt) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int mbase = mt * BKM + b_mb[i] * EPV;
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        const int m = mbase + e;
-        bool v = b_cvalid[i] && m < p.M;
-        if (b_op[i] == 0) {
-          if (v) blk[i].load_row(e, DY + (size_t)m * p.Cout + n0 + b_cc[i] * EPV);
-          else blk[i].zero_row(e);
-        } else {
-          size_t off;
-          if (MODE == MODE_1x1) {
-            off = (size_t)m * p.Cin + b_cin[i];
-          } else {
-            const int hw = p.Ho * p.Wo;
-            const int n = m / hw, r = m - n * hw;
-            const int oh = r / p.Wo, ow = r - oh * p.Wo;
-            const int kh = (b_tap[i] * 11) >> 5, kw = b_tap[i] - 3 * kh;
-            const int ih = oh * p.stride + kh - 1, iw = ow * p.stride + kw - 1;
-            v = v && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-            off = (size_t)((n * p.H + ih) * p.W + iw) * p.Cin + b_cin[i];
-          }
-          if (v) blk[i].load_row(e, X + off);
-          else blk[i].zero_row(e);
-        }
-      }
-    }
-  };
-  auto store_tile = [&](char* stage) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      char* base = stage + b_op[i] * A_BYTES;
-#pragma unroll
-      for (int c = 0; c < EPV; ++c) {
-        const int row = b_cc[i] * EPV + c;
-        *reinterpret_cast<uint4*>(base + lds_chunk_off(row, b_mb[i])) = blk[i].col(c);
-      }
-    }
-  };
+// Straight-line (select-only) gather: the operand role of a block (dY rows vs im2col rows) is folded into
+// address selects, so the EPV loads of a block issue back to back and are waited for once.
+#define MDM_WG_LOAD(mt)                                                                                  \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                     \
+      const bool is_a = b_op[i] == 0;                                                                    \
+      const T* base = is_a ? DY : X;                                                                     \
+      const int mbase = (mt) * BKM + b_mb[i] * EPV;                                                      \
+      int pn = 0, poh = 0, pow_ = 0;                                                                     \
+      if (MODE != MODE_1x1) {                                                                            \
+        const int hw = p.Ho * p.Wo;                                                                      \
+        pn = mbase / hw;                                                                                 \
+        const int r = mbase - pn * hw;                                                                   \
+        poh = r / p.Wo; pow_ = r - poh * p.Wo;                                                           \
+      }                                                                                                  \
+      const int kh = (b_tap[i] * 11) >> 5, kw = b_tap[i] - 3 * kh;                                       \
+      const size_t a_col = (size_t)(n0 + b_cc[i] * EPV);                                                 \
+      _Pragma("unroll") for (int e = 0; e < EPV; ++e) {                                                  \
+        const int m = mbase + e;                                                                         \
+        bool v = b_cvalid[i] && m < p.M;                                                                 \
+        size_t off_b;                                                                                    \
+        bool vb = true;                                                                                  \
+        if (MODE == MODE_1x1) {                                                                          \
+          off_b = (size_t)m * p.Cin + b_cin[i];                                                          \
+        } else {                                                                                         \
+          const int ih = poh * p.stride + kh - 1, iw = pow_ * p.stride + kw - 1;                         \
+          vb = ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);                         \
+          off_b = (size_t)((pn * p.H + ih) * p.W + iw) * p.Cin + b_cin[i];                               \
+          const bool wrap_w = (pow_ + 1 == p.Wo);                                                        \
+          const bool wrap_h = wrap_w && (poh + 1 == p.Ho);                                               \
+          pow_ = wrap_w ? 0 : pow_ + 1;                                                                  \
+          poh = wrap_h ? 0 : (wrap_w ? poh + 1 : poh);                                                   \
+          pn = wrap_h ? pn + 1 : pn;                                                                     \
+        }                                                                                                \
+        const size_t off_a = (size_t)m * p.Cout + a_col;                                                 \
+        v = v && (is_a || vb);                                                                           \
+        const size_t off = is_a ? off_a : off_b;                                                         \
+        blk[i].load_row_sel(e, base + (v ? off : (size_t)0), v);                                         \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+#define MDM_WG_STORE(stage)                                                                              \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                     \
+      char* base = (stage) + b_op[i] * A_BYTES;                                                          \
+      _Pragma("unroll") for (int c = 0; c < EPV; ++c) {                                                  \
+        const int row = b_cc[i] * EPV + c;                                                               \
+        *reinterpret_cast<uint4*>(base + lds_chunk_off(row, b_mb[i])) = blk[i].col(c);                   \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -334,14 +347,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (mt_begin < mt_end) {
-    load_tile(mt_begin);
-    store_tile(smem);
+    MDM_WG_LOAD(mt_begin);
+    MDM_WG_STORE(smem);
     __syncthreads();
     for (int mt = mt_begin; mt < mt_end; ++mt) {
       const int it = mt - mt_begin;
       char* cur = smem + (it & 1) * STAGE;
       const bool more = mt + 1 < mt_end;
-      if (more) load_tile(mt + 1);
+      if (more) MDM_WG_LOAD(mt + 1);
       const char* As = cur;
       const char* Bs = cur + A_BYTES;
 #pragma unroll
@@ -356,12 +369,227 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
       }
-      if (more) store_tile(smem + ((it + 1) & 1) * STAGE);
+      if (more) MDM_WG_STORE(smem + ((it + 1) & 1) * STAGE);
       __syncthreads();
     }
   }
+#undef MDM_WG_LOAD
+#undef MDM_WG_STORE
 
   // acc[i][j][e] = dW[n = n0 + wm*64 + i*16 + l16][k = k0 + wn*64 + j*16 + quad*4 + e]
+  float* __restrict__ S = p.slab + (size_t)split * p.Cout * p.K;
+  const bool vec_ok = (p.K & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int n = n0 + wm * TM + i * 16 + l16;
+    if (n >= p.Cout) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int k = k0 + wn * TN + j * 16 + quad * 4;
+      if (k >= p.K) continue;
+      float* o = S + (size_t)n * p.K + k;
+      if (vec_ok) {
+        *reinterpret_cast<f32x4*>(o) = acc[i][j];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k + e < p.K) o[e] = acc[i][j][e];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bf16 wgrad, LDS-DMA + transpose-read variant.  Both operands are staged in their NATURAL layout
+// ([64 pixels][128 channels], 256-byte rows) straight from HBM by global_load_lds -- no staging registers, no
+// in-register transposes, no ds_write pass -- and the MFMA fragments (8 consecutive *pixels* of one channel)
+// are assembled by the LDS transpose read ds_read_b64_tr_b16: in a 16-lane group lane i supplies the address
+// of row (i >> 2), 4-element column segment (i & 3) of a 4 x 16 block and receives column i (probe:
+// tools/probes/ds_read_tr_probe.hip).  Rows are swizzled at 32-byte granularity,
+// seg' = seg ^ ((row & 3) | ((row >> 3) & 1) << 2), which makes the 8 rows a half-wave touches land on 8
+// distinct 32-byte bank groups; the DMA applies the inverse permutation on the source address.
+// ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ int tr_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+// Eight transpose-read fragments (4 of operand A, 4 of operand B) of one 32-pixel k-step, issued as ONE asm
+// statement with its own lgkmcnt wait.  Inline asm on purpose: for the ds_read_tr builtin hipcc assumes the read
+// may alias an in-flight LDS-DMA and drains vmcnt(0) in front of it, which would serialise the next tile's
+// global_load_lds behind this tile's MFMAs (cdna_hip_programming.md section 5.7).  Here the reads only ever touch
+// the buffer that the previous __syncthreads() (vmcnt(0) + barrier) completed.
+// a0..a3 / b0..b3: per-lane byte addresses (LDS) of fragment column tiles 0..3 for reduction row quad*8 + (l16>>2);
+// OFF = compile-time byte offset of the k-step inside the tile (ks * 32 rows * 256 B).
+template <int OFF>
+__device__ __forceinline__ void load_frags_tr(Frag<bf16> (&af)[4], Frag<bf16> (&bf_)[4], unsigned a0, unsigned a1,
+                                              unsigned a2, unsigned a3, unsigned b0, unsigned b1, unsigned b2,
+                                              unsigned b3) {
+  s16x4 r[16];
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %1, %16 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %2, %17 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %3, %17 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %4, %18 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %5, %18 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %6, %19 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %7, %19 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %8, %20 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %9, %20 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %10, %21 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %11, %21 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %12, %22 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %13, %22 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %14, %23 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %15, %23 offset:%25\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+        "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "i"(OFF), "i"(OFF + 1024)
+      : "memory");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s16x8 va = {r[2 * i][0], r[2 * i][1], r[2 * i][2], r[2 * i][3], r[2 * i + 1][0], r[2 * i + 1][1], r[2 * i + 1][2], r[2 * i + 1][3]};
+    af[i].v = *reinterpret_cast<bf16x8*>(&va);
+    s16x8 vb = {r[8 + 2 * i][0], r[8 + 2 * i][1], r[8 + 2 * i][2], r[8 + 2 * i][3], r[9 + 2 * i][0], r[9 + 2 * i][1], r[9 + 2 * i][2], r[9 + 2 * i][3]};
+    bf_[i].v = *reinterpret_cast<bf16x8*>(&vb);
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs p) {
+  typedef bf16 T;
+  constexpr int EPV = 8, BKM = 64;
+  constexpr int BM = 128, BN = 128, TM = 64, TN = 64, MT = 4, NT = 4;
+  constexpr int A_BYTES = BKM * 256, STAGE = 2 * A_BYTES;   // 16 KB per operand
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int quad = lane >> 4, l16 = lane & 15;
+
+  const int tiles_k = (p.K + BN - 1) / BN;
+  const int tiles_n = (p.Cout + BM - 1) / BM;
+  const int tiles = tiles_k * tiles_n;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lid / tiles;
+  const int t = lid - split * tiles;
+  const int n0 = (t / tiles_k) * BM, k0 = (t % tiles_k) * BN;
+
+  const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+
+  // staging role of this thread: physical 16-byte slot `ps` of rows (j*16 + wave*4 + quad), j = 0..3
+  const int ps = l16;
+  const int srow = wave * 4 + quad;                          // + 16 j
+  const int lc = ((((ps >> 1) ^ tr_swz(srow)) << 1) | (ps & 1));   // logical chunk (same for every j: 16 j keeps bits 0-1,3... see note)
+  // note: tr_swz uses row bits 0,1,3; rows srow + 16 j share them, so one logical chunk serves all four passes
+  const int a_col = n0 + lc * EPV;
+  const bool a_ok = a_col < p.Cout;
+  const int kk = k0 + lc * EPV;
+  const bool b_ok = kk < p.K;
+  int tap = 0, cin = kk;
+  if (MODE != MODE_1x1) { tap = kk / p.Cin; cin = kk - tap * p.Cin; }
+  const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
+  const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
+
+  const int mt_begin = split * p.mtiles_per_split;
+  const int mt_total = (p.M + BKM - 1) / BKM;
+  const int mt_end = min(mt_total, mt_begin + p.mtiles_per_split);
+
+  // pixel coordinates of the 4 staged rows of the next tile to be issued
+  int pn[4], poh[4], pow_[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = mt_begin * BKM + j * 16 + srow;
+    if (MODE != MODE_1x1) {
+      const int hw = p.Ho * p.Wo;
+      pn[j] = m / hw;
+      const int r = m - pn[j] * hw;
+      poh[j] = r / p.Wo; pow_[j] = r - poh[j] * p.Wo;
+    } else { pn[j] = 0; poh[j] = 0; pow_[j] = 0; }
+  }
+  int m_next = mt_begin * BKM;
+
+#define MDM_GLDS(src, lds_off)                                                                            \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                  \
+                                   (__attribute__((address_space(3))) void*)(lds_off), 16, 0, 0)
+#define MDM_WG_STAGE(stage)                                                                               \
+  {                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
+      const int m = m_next + j * 16 + srow;                                                               \
+      const bool mv = m < p.M;                                                                            \
+      const T* sa = (mv && a_ok) ? DY + (size_t)m * p.Cout + a_col : reinterpret_cast<const T*>(g_zero_page); \
+      MDM_GLDS(sa, (stage) + j * 4096 + wave_lds);                                                        \
+      bool v = mv && b_ok;                                                                                \
+      size_t off;                                                                                         \
+      if (MODE == MODE_1x1) {                                                                             \
+        off = (size_t)m * p.Cin + cin;                                                                    \
+      } else {                                                                                            \
+        const int ih = poh[j] * p.stride + kh - 1, iw = pow_[j] * p.stride + kw - 1;                      \
+        v = v && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);                        \
+        off = (size_t)((pn[j] * p.H + ih) * p.W + iw) * p.Cin + cin;                                      \
+        pow_[j] += BKM;                                                                                   \
+        while (pow_[j] >= p.Wo) { pow_[j] -= p.Wo; ++poh[j]; }                                            \
+        while (poh[j] >= p.Ho) { poh[j] -= p.Ho; ++pn[j]; }                                               \
+      }                                                                                                   \
+      const T* sb = v ? X + off : reinterpret_cast<const T*>(g_zero_page);                                \
+      MDM_GLDS(sb, (stage) + A_BYTES + j * 4096 + wave_lds);                                              \
+    }                                                                                                     \
+    m_next += BKM;                                                                                        \
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane LDS byte addresses of the transpose reads: reduction row quad*8 + (l16>>2) (+4 for the upper half,
+  // +32 rows per k-step: immediates), 16-channel column tile `c`, 4-element segment l16 & 3
+  unsigned fa[4], fb[4];
+  {
+    const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int r0 = quad * 8 + (l16 >> 2);
+    const int fsw = (l16 >> 2) | ((quad & 1) << 2);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      fa[c] = smem_base + r0 * 256 + (((wm * 4 + c) ^ fsw) << 5) + ((l16 & 3) << 3);
+      fb[c] = smem_base + A_BYTES + r0 * 256 + (((wn * 4 + c) ^ fsw) << 5) + ((l16 & 3) << 3);
+    }
+  }
+
+  if (mt_begin < mt_end) {
+    MDM_WG_STAGE(smem);
+    __syncthreads();
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
+      const int it = mt - mt_begin;
+      char* cur = smem + (it & 1) * STAGE;
+      if (mt + 1 < mt_end) MDM_WG_STAGE(smem + ((it + 1) & 1) * STAGE);
+      const unsigned so = (unsigned)((it & 1) * STAGE);
+      {
+        Frag<T> af[MT], bfr[NT];
+        load_frags_tr<0>(af, bfr, fa[0] + so, fa[1] + so, fa[2] + so, fa[3] + so, fb[0] + so, fb[1] + so, fb[2] + so, fb[3] + so);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
+      }
+      {
+        Frag<T> af[MT], bfr[NT];
+        load_frags_tr<8192>(af, bfr, fa[0] + so, fa[1] + so, fa[2] + so, fa[3] + so, fb[0] + so, fb[1] + so, fb[2] + so, fb[3] + so);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
+      }
+      __syncthreads();
+    }
+  }
+#undef MDM_WG_STAGE
+#undef MDM_GLDS
+
   float* __restrict__ S = p.slab + (size_t)split * p.Cout * p.K;
   const bool vec_ok = (p.K & 3) == 0;
 #pragma unroll
@@ -424,49 +652,46 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
-// Column sums: out[c] = sum_m x[m, c]  (bias gradients).  Two deterministic stages.
+// Column sums: out[c] = sum_m x[m, c]  (bias gradients).  Two deterministic stages: a
+// (column group) x (row slab) grid of partial sums, then a per-channel sum over the slabs.
+// A block is 8 chunk columns (128 bytes of a row) x 32 row lanes.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ part,
-                                                             int M, int C, int rows_per_block) {
+                                                             int M, int C, int rows_per_slab) {
   constexpr int EPV = Tr<T>::EPV;
-  __shared__ float red[256 * 8];
-  const int nchunks = C / EPV;                 // host guarantees C % EPV == 0
-  const int tid = threadIdx.x;
-  const int m_begin = blockIdx.x * rows_per_block, m_end = min(M, m_begin + rows_per_block);
-  for (int c0 = 0; c0 < nchunks; c0 += 256) {
-    // threads: tc = chunk lane, tr = row lane; nchunks may be < 256 -> several rows per pass
-    const int cw = min(256, nchunks - c0);
-    const int rows_par = 256 / cw;             // >= 1
-    const int tc = tid % cw, tr = tid / cw;
-    float s[EPV];
+  __shared__ float red[32][8][8];
+  const int tid = threadIdx.x, tc = tid & 7, tr = tid >> 3;
+  const int chunk = blockIdx.x * 8 + tc;
+  const bool cok = chunk * EPV < C;
+  const int m_begin = blockIdx.y * rows_per_slab, m_end = min(M, m_begin + rows_per_slab);
+  float s[EPV];
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) s[e] = 0.f;
-    if (tr < rows_par) {
-      for (int m = m_begin + tr; m < m_end; m += rows_par) {
-        Chunk<T> ch;
-        ch.load(x + (size_t)m * C + (size_t)(c0 + tc) * EPV);
+  for (int e = 0; e < EPV; ++e) s[e] = 0.f;
+  if (cok) {
+    for (int m = m_begin + tr; m < m_end; m += 32) {
+      Chunk<T> ch;
+      ch.load(x + (size_t)m * C + (size_t)chunk * EPV);
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) s[e] += ch.v[e];
-      }
+      for (int e = 0; e < EPV; ++e) s[e] += ch.v[e];
     }
+  }
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) red[tid * 8 + e] = s[e];
-    __syncthreads();
-    if (tr == 0) {
-      for (int r = 1; r < rows_par; ++r)
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) s[e] += red[(r * cw + tc) * 8 + e];
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) part[(size_t)blockIdx.x * C + (size_t)(c0 + tc) * EPV + e] = s[e];
-    }
-    __syncthreads();
+  for (int e = 0; e < EPV; ++e) red[tr][tc][e] = s[e];
+  __syncthreads();
+  if (tid < 8 * EPV) {
+    const int c = tid / EPV, e = tid - c * EPV;
+    float a = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) a += red[r][c][e];
+    const int ch = (blockIdx.x * 8 + c) * EPV + e;
+    if (ch < C) part[(size_t)blockIdx.y * C + ch] = a;
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C) {
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nslabs, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * C + c];
+  for (int b = 0; b < nslabs; ++b) s += part[(size_t)b * C + c];
   out[c] = s;
 }
 
@@ -569,8 +794,8 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, flo
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<float, MODE_1x1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<float, MODE_3x3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<bf16, MODE_1x1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<bf16, MODE_3x3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tr_kernel<MODE_1x1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tr_kernel<MODE_3x3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_done = true;
   }
   dim3 grid(tiles * a.splits), block(256);
@@ -578,8 +803,8 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, flo
     if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_kernel<float, MODE_1x1>), grid, block, smem, st, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<float, MODE_3x3>), grid, block, smem, st, a);
   } else {
-    if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_kernel<bf16, MODE_1x1>), grid, block, smem, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<bf16, MODE_3x3>), grid, block, smem, st, a);
+    if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_1x1>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_3x3>), grid, block, smem, st, a);
   }
   const size_t total = (size_t)Cout * a.K;
   const int rb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
@@ -604,29 +829,37 @@ extern "C" int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, 
   MDM_LAUNCH_STATUS();
 }
 
+static inline int colsum_slabs(int M, int C, int epv) {
+  const int groups = (C + 8 * epv - 1) / (8 * epv);
+  int slabs = (1024 + groups - 1) / groups;
+  const int max_slabs = (M + 63) / 64;
+  if (slabs > max_slabs) slabs = max_slabs;
+  if (slabs > 64) slabs = 64;
+  if (slabs < 1) slabs = 1;
+  return slabs;
+}
+
 extern "C" int mdm_colsum_plan(int M, int C, int* nblocks, size_t* ws_bytes) {
   MDM_CHECK_ARG(nblocks && ws_bytes);
-  int nb = (M + 127) / 128;
-  if (nb > 512) nb = 512;
-  if (nb < 1) nb = 1;
-  *nblocks = nb;
-  *ws_bytes = (size_t)nb * C * sizeof(float);
+  const int slabs = colsum_slabs(M, C, 4);  // upper bound over both dtypes
+  *nblocks = slabs;
+  *ws_bytes = (size_t)64 * C * sizeof(float);
   return 0;
 }
 
 extern "C" int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int dtype, void* stream) {
   MDM_CHECK_ARG(x && out && ws);
+  MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
   const int epv = dtype == DT_F32 ? 4 : 8;
   MDM_CHECK_ARG(C % epv == 0);
-  int nb; size_t wsb;
-  mdm_colsum_plan(M, C, &nb, &wsb);
-  const int rpb = (M + nb - 1) / nb;
-  nb = (M + rpb - 1) / rpb;
+  const int slabs = colsum_slabs(M, C, epv);
+  const int rps = (M + slabs - 1) / slabs;
+  const int groups = (C + 8 * epv - 1) / (8 * epv);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DT_F32)
-    hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, ws, M, C, rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(groups, slabs), dim3(256), 0, st, (const float*)x, ws, M, C, rps);
   else
-    hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x, ws, M, C, rpb);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, out, nb, C);
+    hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(groups, slabs), dim3(256), 0, st, (const bf16*)x, ws, M, C, rps);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, out, slabs, C);
   MDM_LAUNCH_STATUS();
 }

@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Per-shape timing of the GEMM-class kernels on the UNet-64 (batch 64) shapes.  Development tool:
+   gpurun -- python tools/kbench.py [fwd|wgrad|attn|all]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ml-mdm_amd"))
+import torch  # noqa: E402
+
+from mdm_hip import ops  # noqa: E402
+
+B = int(os.environ.get("KB_BATCH", "64"))
+DT = torch.bfloat16 if os.environ.get("KB_DTYPE", "bf16") == "bf16" else torch.float32
+dev = torch.device("cuda:0")
+
+# (name, H, Cin, Cout, ks, stride)
+SHAPES = [
+    ("3x3 256->256 @64", 64, 256, 256, 3, 1),
+    ("3x3 512->512 @32", 32, 512, 512, 3, 1),
+    ("3x3 768->768 @16", 16, 768, 768, 3, 1),
+    ("3x3 512->256 @64", 64, 512, 256, 3, 1),
+    ("3x3 1536->768 @16", 16, 1536, 768, 3, 1),
+    ("3x3 1280->512 @32", 32, 1280, 512, 3, 1),
+    ("3x3s2 256->256 @64", 64, 256, 256, 3, 2),
+    ("1x1 768->3072 @16", 16, 768, 3072, 1, 1),
+    ("1x1 3072->768 @16", 16, 3072, 768, 1, 1),
+    ("1x1 768->2304 @16", 16, 768, 2304, 1, 1),
+    ("1x1 768->768 @16", 16, 768, 768, 1, 1),
+    ("1x1 512->2048 @32", 32, 512, 2048, 1, 1),
+    ("1x1 512->1536 @32", 32, 512, 1536, 1, 1),
+]
+
+
+def timeit(fn, iters=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    for name, H, cin, cout, ks, stride in SHAPES:
+        x = torch.randn(B, H, H, cin, device=dev).to(DT)
+        w = (torch.randn(cout, cin, ks, ks, device=dev) / (cin * ks * ks) ** 0.5)
+        b = torch.randn(cout, device=dev)
+        wf, wd, bp, cin_p, cout_p = ops.packed_weight(w, b, DT)
+        Ho = (H - 1) // stride + 1
+        y = torch.empty(B, Ho, Ho, cout, device=dev, dtype=DT)
+        flops = 2.0 * B * Ho * Ho * cout * cin * ks * ks
+        line = "%-22s" % name
+        if what in ("fwd", "all"):
+            t = timeit(lambda: ops._conv_launch(x, wf, bp, None, None, y, None, B, H, H, cin, Ho, Ho, cout, ks, stride, 0, 0))
+            line += "  fwd %7.3f ms %7.1f TF" % (t * 1e3, flops / t / 1e12)
+        if what in ("dgrad", "all") and stride == 1:
+            dx = torch.empty_like(x)
+            t = timeit(lambda: ops._conv_launch(y, wd, None, None, None, dx, None, B, Ho, Ho, cout, H, H, cin, ks, 1, 0, 0))
+            line += "  dgrad %7.3f ms %7.1f TF" % (t * 1e3, flops / t / 1e12)
+        if what in ("wgrad", "all"):
+            t = timeit(lambda: ops._wgrad_launch(x, y, B, H, H, cin, Ho, Ho, cout, ks, stride))
+            line += "  wgrad %7.3f ms %7.1f TF" % (t * 1e3, flops / t / 1e12)
+        print(line, flush=True)
+    if what in ("attn", "all"):
+        for L, d in ((1024, 64), (256, 96)):
+            C = 8 * d
+            qkv = torch.randn(B, L, 3 * C, device=dev).to(DT).requires_grad_()
+            kvc = torch.randn(B, 32, 2 * C, device=dev).to(DT).requires_grad_()
+            fl = 4.0 * B * 8 * L * (L + 32) * d
+            t = timeit(lambda: ops.attention(qkv.detach(), kvc.detach(), None, 8))
+            o = ops.attention(qkv, kvc, None, 8)
+            go = torch.randn_like(o)
+            tb = timeit(lambda: torch.autograd.grad(o, (qkv, kvc), go, retain_graph=True))
+            print("attn L=%d d=%d  fwd %7.3f ms %6.1f TF   bwd %7.3f ms %6.1f TF" % (L, d, t * 1e3, fl / t / 1e12, tb * 1e3, 2.5 * fl / tb / 1e12), flush=True)
+
+
+if __name__ == "__main__":
+    main()
