@@ -165,11 +165,69 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 #undef MDM_GLDS
 
   // ---- epilogue -------------------------------------------------------------
+  // bias / activation / residual are applied in registers (fp32); the finished tile is then staged through
+  // LDS (free after the k-loop) so that HBM sees whole 16-byte chunks of complete output rows instead of the
+  // 8-byte-per-lane fragments of the MFMA layout (the output-heavy 1x1 convs -- qkv, FFN up -- were store-bound).
   T* __restrict__ Y = reinterpret_cast<T*>(p.y);
   T* __restrict__ Ypre = reinterpret_cast<T*>(p.ypre);
   const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
   const T* __restrict__ AUX = reinterpret_cast<const T*>(p.aux);
-  const bool vec_ok = (p.Cout & 3) == 0;
+  constexpr int PITCH = sizeof(T) == 2 ? BN * 2 + 16 : BN * 4;   // bytes per staged row
+  static_assert(BM * PITCH <= 2 * STAGE, "output tile must fit the k-loop LDS");
+  constexpr int OCH = BN / EPV;                                    // 16-byte chunks per staged row
+  if ((p.Cout % EPV) == 0) {
+    const int first_pass = (p.act == 1 && Ypre) ? 0 : 1;
+    for (int pass = first_pass; pass < 2; ++pass) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int ml = wm * TM + i * 16 + l16, m = m0 + ml;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int nl = wn * TN + j * 16 + quad * 4, n = n0 + nl;
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          const bool live = m < p.M && n < p.Cout;   // Cout % 4 == 0 here: all four or none
+          if (live) {
+            const size_t o = (size_t)m * p.Cout + n;
+            if (p.bias) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bv[e];
+            }
+            if (pass == 1) {
+              if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+              } else if (p.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(to_f32(AUX[o + e]));
+              }
+              if (R) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += to_f32(R[o + e]);
+              }
+            }
+          }
+          char* dst = smem + ml * PITCH + nl * (int)sizeof(T);
+          if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+          } else {
+            *reinterpret_cast<bf16x4*>(dst) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          }
+        }
+      }
+      __syncthreads();
+      T* __restrict__ OUT = pass == 0 ? Ypre : Y;
+      for (int idx = tid; idx < BM * OCH; idx += 256) {
+        const int row = idx / OCH, ch = idx - row * OCH;
+        const int m = m0 + row, n = n0 + ch * EPV;
+        if (m < p.M && n < p.Cout)
+          *reinterpret_cast<uint4*>(OUT + (size_t)m * p.Cout + n) = *reinterpret_cast<const uint4*>(smem + row * PITCH + ch * 16);
+      }
+      if (pass == 0) __syncthreads();
+    }
+    return;
+  }
+  // generic path (Cout not a multiple of the chunk): per-element stores
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + wm * TM + i * 16 + l16;
@@ -180,36 +238,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
       if (n >= p.Cout) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       const size_t o = (size_t)m * p.Cout + n;
-      const int nv = vec_ok ? 4 : min(4, p.Cout - n);
-      if (p.bias) {
+      const int nv = min(4, p.Cout - n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) v[e] += p.bias[n + e];
-      }
-      if (p.act == 1) {
-        if (Ypre) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (e < nv) Ypre[o + e] = from_f32<T>(v[e]);
+      for (int e = 0; e < 4; ++e) {
+        if (e >= nv) continue;
+        if (p.bias) v[e] += p.bias[n + e];
+        if (p.act == 1) {
+          if (Ypre) Ypre[o + e] = from_f32<T>(v[e]);
+          v[e] = gelu_f(v[e]);
+        } else if (p.act == 2) {
+          v[e] *= dgelu_f(to_f32(AUX[o + e]));
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-      } else if (p.act == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) v[e] *= dgelu_f(to_f32(AUX[o + e]));
-      }
-      if (R) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) v[e] += to_f32(R[o + e]);
-      }
-      if (vec_ok) {
-        if constexpr (sizeof(T) == 4) {
-          *reinterpret_cast<f32x4*>(Y + o) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          bf16x4 b = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          *reinterpret_cast<bf16x4*>(Y + o) = b;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) Y[o + e] = from_f32<T>(v[e]);
+        if (R) v[e] += to_f32(R[o + e]);
+        Y[o + e] = from_f32<T>(v[e]);
       }
     }
   }
