@@ -130,6 +130,8 @@ class GradReducer:
     def finish(self):
         """join the outstanding all-reduces; afterwards every p.grad holds the rank-average"""
         if self.world > 1 and self._enabled:
+            if self._pending == self._need and not self._work:
+                return  # no synchronised backward since the last finish()
             missing = [b for b, n in enumerate(self._pending) if n != 0]
             if missing:
                 raise RuntimeError("buckets %s did not receive all their gradients (unused parameters?)" % missing)

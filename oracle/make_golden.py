@@ -70,5 +70,111 @@ def main():
               [float(o.abs().mean()) for o in blob["outputs"]])
 
 
+def diffusion_host_golden():
+    """outputs of the reference's Sampler / Diffusion / NestedDiffusion driven by tests/stub_models.py"""
+    import numpy as np
+
+    import stub_models as SM
+
+    R = ref_import.load()
+    S, D = R.samplers, R.diffusion
+    blob = {"schedules": {}}
+    for st in ("COSINE", "DDPM", "DEEPFLOYD"):
+        smp = S.Sampler(S.SamplerConfig(num_diffusion_steps=1000, schedule_type=S.ScheduleType[st]))
+        blob["schedules"][st] = {"gammas": smp.gammas.clone(), "vdm": smp.vdm_loss_weights.clone()}
+    blob["timesteps_250"] = smp.set_timesteps(250)
+
+    def sc(**kw):
+        base = dict(num_diffusion_steps=1000, schedule_type=S.ScheduleType.DEEPFLOYD,
+                    prediction_type=S.PredictionType.V_PREDICTION, loss_target_type=S.PredictionType.DDPM,
+                    threshold_function=S.ThresholdType.CLIP)
+        base.update(kw)
+        return S.SamplerConfig(**base)
+
+    g = torch.Generator().manual_seed(7)
+    sample = {"images": torch.rand(3, 3, 16, 16, generator=g) * 2 - 1, "lm_outputs": torch.randn(3, 5, 8, generator=g),
+              "lm_mask": torch.ones(3, 5)}
+    # plain pipeline
+    pipe = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=sc(), use_vdm_loss_weights=False))
+    torch.manual_seed(11)
+    loss, time, x_t, means, tgt, w = pipe.get_loss(sample)
+    blob["loss"] = dict(loss=loss.detach(), time=time, x_t=x_t.detach(), means=means.detach(), tgt=tgt.detach())
+    pipe_v = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=sc(), use_vdm_loss_weights=True))
+    torch.manual_seed(11)
+    blob["loss_vdm_weights"] = pipe_v.get_loss(sample)[5].detach()
+    for tag, kw in (("ddim", dict(ddim_eta=0)), ("ddpm", dict()), ("ddim_cfg", dict(ddim_eta=0, guidance_scale=3.0)),
+                    ("ddpm_eta1_dyn", dict(ddim_eta=1))):
+        cfg = sc(threshold_function=S.ThresholdType.DYNAMIC) if tag.endswith("dyn") else sc()
+        pp = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=cfg, use_vdm_loss_weights=False))
+        smp_in = dict(sample)
+        if "cfg" in tag:
+            smp_in["lm_outputs"] = torch.cat([torch.zeros_like(sample["lm_outputs"]), sample["lm_outputs"]])
+            smp_in["lm_mask"] = torch.cat([sample["lm_mask"]] * 2)
+        torch.manual_seed(13)
+        with torch.no_grad():
+            out = pp.sample(3, smp_in, 16, torch.device("cpu"), resample_steps=True, num_inference_steps=4, **kw)
+        blob["sample_" + tag] = out.detach()
+    # nested pipeline (256-style: shifted schedule, double loss, no residual)
+    ncfg = D.NestedDiffusionConfig(sampler_config=sc(schedule_shifted=True, rescale_signal=1), use_vdm_loss_weights=False,
+                                   use_double_loss=True, no_use_residual=True, multi_res_weights="4:1")
+    npipe = D.NestedDiffusion(SM.StubNestedUNet(), ncfg)
+    nsample = dict(sample, images=torch.rand(3, 3, 32, 32, generator=g) * 2 - 1)
+    torch.manual_seed(17)
+    loss, time, x_t, pred, tgt, w = npipe.get_loss(nsample)
+    blob["nested_loss"] = dict(loss=loss.detach(), time=time, x_t=x_t.detach(), pred=pred.detach(), tgt=tgt.detach())
+    torch.manual_seed(19)
+    with torch.no_grad():
+        out = npipe.sample(3, nsample, 32, torch.device("cpu"), resample_steps=True, num_inference_steps=4, ddim_eta=0)
+    blob["nested_sample_ddim"] = out.detach()
+    torch.manual_seed(19)
+    with torch.no_grad():
+        out = npipe.sample(3, nsample, 32, torch.device("cpu"), resample_steps=True, num_inference_steps=3, output_inner=True)
+    blob["nested_sample_ddpm_inner"] = out.detach()
+    path = os.path.join(ROOT, "tests", "golden", "diffusion_host.pt")
+    torch.save(blob, path)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def sampling_golden():
+    """4-step deterministic (DDIM eta=0) sampling and a train-step loss through the REAL reference pipeline +
+    reference UNet / NestedUNet on the mini cases (BASELINE.json configs[0] shape of test, reduced size)."""
+    R = ref_import.load()
+    S, D = R.samplers, R.diffusion
+    blob = {}
+    for name in ("mini_unet", "mini_nested"):
+        _, cfg, sd = PC.build_module(name)
+        rcfg = to_ref_cfg(R, cfg)
+        nested = hasattr(rcfg, "inner_config")
+        ref = (R.nested_unet.NestedUNet if nested else R.unet.UNet)(3, 3, rcfg)
+        ref.load_state_dict(sd, strict=True)
+        scfg = S.SamplerConfig(num_diffusion_steps=1000, schedule_type=S.ScheduleType.DEEPFLOYD,
+                               prediction_type=S.PredictionType.V_PREDICTION, loss_target_type=S.PredictionType.DDPM,
+                               threshold_function=S.ThresholdType.CLIP, schedule_shifted=nested,
+                               rescale_signal=1 if nested else None)
+        if nested:
+            pipe = D.NestedDiffusion(ref, D.NestedDiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False,
+                                                                  use_double_loss=True, no_use_residual=True))
+        else:
+            pipe = D.Diffusion(ref, D.DiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False))
+        inp = PC.inputs(name)
+        side = 32 if nested else 16
+        smp = {"lm_outputs": inp["cond"], "lm_mask": inp["mask"]}
+        torch.manual_seed(23)
+        with torch.no_grad():
+            img = pipe.sample(2, smp, side, torch.device("cpu"), resample_steps=True, num_inference_steps=4, ddim_eta=0)
+        g = torch.Generator().manual_seed(29)
+        smp["images"] = torch.rand(2, 3, side, side, generator=g) * 2 - 1
+        torch.manual_seed(31)
+        pipe.train()
+        loss = pipe.get_loss(smp)[0]
+        blob[name] = {"sample": img.detach().clone(), "loss": loss.detach().clone()}
+        print(name, "sample", tuple(img.shape), "loss", loss.tolist())
+    path = os.path.join(ROOT, "tests", "golden", "pipeline.pt")
+    torch.save(blob, path)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     main()
+    diffusion_host_golden()
+    sampling_golden()

@@ -1,0 +1,137 @@
+"""CPU: the diffusion / sampler call-surface mirrors (mdm_hip.diffusion, mdm_hip.samplers) reproduce the
+reference's Sampler / Diffusion / NestedDiffusion, checked against golden outputs produced by the real
+reference (oracle/make_golden.py: diffusion_host_golden) with the same stub vision model and CPU RNG seed."""
+import os
+
+import pytest
+import torch
+
+import stub_models as SM
+import unet_oracle as O
+
+GOLD = torch.load(os.path.join(os.path.dirname(__file__), "golden", "diffusion_host.pt"), weights_only=False)
+
+
+def sc(**kw):
+    from mdm_hip import samplers as S
+
+    base = dict(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
+                loss_target_type="DDPM", threshold_function="CLIP")
+    base.update(kw)
+    return S.SamplerConfig(**base)
+
+
+def batch():
+    g = torch.Generator().manual_seed(7)
+    s = {"images": torch.rand(3, 3, 16, 16, generator=g) * 2 - 1, "lm_outputs": torch.randn(3, 5, 8, generator=g),
+         "lm_mask": torch.ones(3, 5)}
+    return s, g
+
+
+@pytest.mark.parametrize("st", ["COSINE", "DDPM", "DEEPFLOYD"])
+def test_noise_schedules(st):
+    from mdm_hip import samplers as S
+
+    smp = S.Sampler(S.SamplerConfig(num_diffusion_steps=1000, schedule_type=st))
+    assert torch.equal(smp.gammas, GOLD["schedules"][st]["gammas"])
+    assert torch.allclose(smp.vdm_loss_weights, GOLD["schedules"][st]["vdm"], rtol=1e-6, atol=0)
+    assert (smp.set_timesteps(250) == GOLD["timesteps_250"]).all()
+
+
+def test_get_loss_matches_reference():
+    from mdm_hip import diffusion as D
+
+    sample, _ = batch()
+    pipe = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=sc(), use_vdm_loss_weights=False))
+    torch.manual_seed(11)
+    loss, time, x_t, means, tgt, w = pipe.get_loss(sample)
+    g = GOLD["loss"]
+    assert w is None and torch.equal(time, g["time"])
+    for a, b in ((loss, g["loss"]), (x_t, g["x_t"]), (means, g["means"]), (tgt, g["tgt"])):
+        assert O.rel_l2(a, b) < 1e-6
+    pipe_v = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=sc(), use_vdm_loss_weights=True))
+    torch.manual_seed(11)
+    assert torch.allclose(pipe_v.get_loss(sample)[5], GOLD["loss_vdm_weights"])
+
+
+@pytest.mark.parametrize("tag,kw", [("ddim", dict(ddim_eta=0)), ("ddpm", dict()),
+                                    ("ddim_cfg", dict(ddim_eta=0, guidance_scale=3.0)),
+                                    ("ddpm_eta1_dyn", dict(ddim_eta=1))])
+def test_sampling_loop_matches_reference(tag, kw):
+    from mdm_hip import diffusion as D
+
+    sample, _ = batch()
+    cfg = sc(threshold_function="DYNAMIC") if tag.endswith("dyn") else sc()
+    pipe = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=cfg, use_vdm_loss_weights=False))
+    if "cfg" in tag:
+        sample["lm_outputs"] = torch.cat([torch.zeros_like(sample["lm_outputs"]), sample["lm_outputs"]])
+        sample["lm_mask"] = torch.cat([sample["lm_mask"]] * 2)
+    torch.manual_seed(13)
+    with torch.no_grad():
+        out = pipe.sample(3, sample, 16, torch.device("cpu"), resample_steps=True, num_inference_steps=4, **kw)
+    assert O.rel_l2(out, GOLD["sample_" + tag]) < 1e-5
+
+
+def test_nested_pipeline_matches_reference():
+    from mdm_hip import diffusion as D
+
+    sample, g = batch()
+    ncfg = D.NestedDiffusionConfig(sampler_config=sc(schedule_shifted=True, rescale_signal=1), use_vdm_loss_weights=False,
+                                   use_double_loss=True, no_use_residual=True, multi_res_weights="4:1")
+    pipe = D.NestedDiffusion(SM.StubNestedUNet(), ncfg)
+    nsample = dict(sample, images=torch.rand(3, 3, 32, 32, generator=g) * 2 - 1)
+    torch.manual_seed(17)
+    loss, time, x_t, pred, tgt, w = pipe.get_loss(nsample)
+    gl = GOLD["nested_loss"]
+    assert torch.equal(time, gl["time"])
+    for a, b in ((loss, gl["loss"]), (x_t, gl["x_t"]), (pred, gl["pred"]), (tgt, gl["tgt"])):
+        assert O.rel_l2(a, b) < 1e-6
+    torch.manual_seed(19)
+    with torch.no_grad():
+        out = pipe.sample(3, nsample, 32, torch.device("cpu"), resample_steps=True, num_inference_steps=4, ddim_eta=0)
+    assert O.rel_l2(out, GOLD["nested_sample_ddim"]) < 1e-5
+    torch.manual_seed(19)
+    with torch.no_grad():
+        out = pipe.sample(3, nsample, 32, torch.device("cpu"), resample_steps=True, num_inference_steps=3, output_inner=True)
+    assert out.shape == GOLD["nested_sample_ddpm_inner"].shape
+    assert O.rel_l2(out, GOLD["nested_sample_ddpm_inner"]) < 1e-5
+
+
+def test_train_step_runs_on_cpu_stub():
+    """TrainStep glue (loss -> backward -> clip -> AdamW -> EMA) with the stub model, fp32 on CPU"""
+    from mdm_hip import diffusion as D
+    from mdm_hip.trainer import TrainStep
+
+    sample, _ = batch()
+    pipe = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=sc(), use_vdm_loss_weights=False))
+    step = TrainStep(pipe, bf16=False, lr=1e-2)
+    w0 = float(pipe.get_model().vision_model.w)
+    l0 = step(sample, time=torch.tensor(500))
+    for _ in range(20):
+        l1 = step(sample, time=torch.tensor(500))
+    assert l1 < l0 and float(pipe.get_model().vision_model.w) != w0
+    assert abs(float(step.ema[0]) - w0) < abs(float(pipe.get_model().vision_model.w) - w0)
+
+
+@pytest.mark.reference
+def test_registry_install_replaces_reference_models():
+    import ref_import
+
+    R = ref_import.load()
+    import mdm_hip
+    from mdm_hip import registry
+
+    prev = registry.install(R.config)
+    try:
+        assert R.config.get_model("unet") is mdm_hip.UNet
+        assert R.config.get_model("nested2_unet") is mdm_hip.NestedUNet
+        # the reference's own config dataclass constructs our model (tests/test_models.py:33-44 of the reference)
+        for name in ("unet", "nested_unet"):
+            cfg_cls = R.config.MODEL_CONFIG_REGISTRY[name]["config"]
+            m = R.config.get_model(name)(input_channels=3, output_channels=3, config=cfg_cls())
+            assert sum(p.numel() for p in m.parameters()) > 0
+        # and the reference pipeline wraps it
+        pipe = R.config.get_pipeline("unet")(mdm_hip.UNet(3, 3, R.unet.UNetConfig()), R.diffusion.DiffusionConfig())
+        assert pipe.get_model().vision_model.model_type == "unet"
+    finally:
+        R.config.MODEL_REGISTRY.update(prev)

@@ -75,3 +75,62 @@ def test_no_grad_inference_matches_training_forward():
         y = model(inp["x"].cuda(), inp["times"].cuda(), inp["cond"].cuda(), inp["mask"].cuda())
     ref, _ = hip_run("mini_unet", torch.float32, with_grad=False)
     assert torch.equal(y.float().cpu(), ref[0])
+
+
+def _pipeline(name, net):
+    from mdm_hip import diffusion as D
+    from mdm_hip import samplers as S
+
+    nested = name == "mini_nested"
+    scfg = S.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
+                           loss_target_type="DDPM", threshold_function="CLIP", schedule_shifted=nested,
+                           rescale_signal=1 if nested else None)
+    if nested:
+        return D.NestedDiffusion(net, D.NestedDiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False,
+                                                              use_double_loss=True, no_use_residual=True))
+    return D.Diffusion(net, D.DiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False))
+
+
+@pytest.mark.parametrize("name", ["mini_unet", "mini_nested"])
+def test_four_step_sampling_and_loss_match_reference_pipeline(name):
+    """Diffusion.sample() (4 DDIM steps) and get_loss() through the HIP denoiser vs the golden images / losses the
+    real reference pipeline produced on CPU with the same seed (tests/golden/pipeline.pt).  Gate: 1e-3 rel-L2
+    (BASELINE.json north_star: "sampled images within 1e-3 rel-L2 of reference")."""
+    gold = torch.load(os.path.join(GOLD, "pipeline.pt"), weights_only=False)[name]
+    model, _, _ = PC.build_module(name)
+    pipe = _pipeline(name, model).to(torch.device("cuda:0"))
+    inp = PC.inputs(name)
+    side = 32 if name == "mini_nested" else 16
+    smp = {"lm_outputs": inp["cond"].cuda(), "lm_mask": inp["mask"].cuda()}
+    torch.manual_seed(23)
+    with torch.no_grad():
+        img = pipe.sample(2, smp, side, torch.device("cuda:0"), resample_steps=True, num_inference_steps=4, ddim_eta=0)
+    assert O.rel_l2(img.cpu(), gold["sample"]) < 1e-3
+    # train-step loss with the reference's timesteps / noise (drawn from the CPU generator exactly as the reference did)
+    g = torch.Generator().manual_seed(29)
+    smp["images"] = (torch.rand(2, 3, side, side, generator=g) * 2 - 1).cuda()
+    torch.manual_seed(31)
+    time = torch.randint(0, 1000, (2,))
+    noise = [torch.randn(2, 3, side, side)] + ([torch.randn(2, 3, side // 2, side // 2)] if name == "mini_nested" else [])
+    it = iter(noise)
+    pipe.train()
+    loss = pipe.get_loss(smp, time=None, noise_fn=lambda like: next(it).to(like.device)) if False else None
+    # get_eps_time draws randint on the images' device in the reference; replay it on CPU by passing explicit values
+    it = iter(noise)
+
+    class _Fixed:
+        pass
+
+    sampler = pipe.sampler
+    orig = sampler.get_eps_time
+
+    def fixed_eps_time(images, t=None, noise_fn=None):
+        tt = time.to(images.device)
+        return next(it).to(images.device), sampler.read_gamma(tt + 1), sampler.read_gamma(tt), sampler.vdm_loss_weights[tt + 1], tt
+
+    sampler.get_eps_time = fixed_eps_time
+    try:
+        loss = pipe.get_loss(smp, noise_fn=lambda like: next(it).to(like.device))[0]
+    finally:
+        sampler.get_eps_time = orig
+    assert O.rel_l2(loss.float().cpu(), gold["loss"]) < 1e-3
