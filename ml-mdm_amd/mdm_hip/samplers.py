@@ -135,8 +135,8 @@ class Sampler(nn.Module):
         B = images.shape[0]
         if time is None:
             time = torch.randint(0, self.n_steps, (B,), device=images.device)
-        else:
-            time = time * torch.ones(B, dtype=torch.long, device=images.device)
+        else:  # scalar or per-sample tensor
+            time = torch.as_tensor(time, device=images.device) * torch.ones(B, dtype=torch.long, device=images.device)
         return noise_fn(images), self.read_gamma(time + 1), self.read_gamma(time), self.vdm_loss_weights[time + 1], time
 
     def get_xt(self, images, eps, g):

@@ -104,33 +104,25 @@ def test_four_step_sampling_and_loss_match_reference_pipeline(name):
     smp = {"lm_outputs": inp["cond"].cuda(), "lm_mask": inp["mask"].cuda()}
     torch.manual_seed(23)
     with torch.no_grad():
-        img = pipe.sample(2, smp, side, torch.device("cuda:0"), resample_steps=True, num_inference_steps=4, ddim_eta=0)
+        if name == "mini_nested":
+            # the reference draws the low-resolution start noise with .normal_() on the sampling device
+            # (samplers.py:669-676); replay its CPU draws and hand the pyramid to the sampler directly
+            pipe.eval()
+            hi = torch.randn(2, 3, side, side)
+            lo = torch.randn(2, 3, side // 2, side // 2)
+            img = pipe.sampler.sample(pipe.get_model(), [hi.cuda(), lo.cuda()], smp["lm_outputs"], smp["lm_mask"], {},
+                                      resample_steps=True, num_inference_steps=4, ddim_eta=0)
+        else:
+            img = pipe.sample(2, smp, side, torch.device("cuda:0"), resample_steps=True, num_inference_steps=4, ddim_eta=0)
     assert O.rel_l2(img.cpu(), gold["sample"]) < 1e-3
-    # train-step loss with the reference's timesteps / noise (drawn from the CPU generator exactly as the reference did)
+    # train-step loss: replay, from the CPU generator, exactly the draws the reference made on CPU
+    # (randint for the timesteps, randn_like for eps, then one normal_() per lower resolution)
     g = torch.Generator().manual_seed(29)
     smp["images"] = (torch.rand(2, 3, side, side, generator=g) * 2 - 1).cuda()
     torch.manual_seed(31)
     time = torch.randint(0, 1000, (2,))
-    noise = [torch.randn(2, 3, side, side)] + ([torch.randn(2, 3, side // 2, side // 2)] if name == "mini_nested" else [])
-    it = iter(noise)
+    draws = [torch.randn(2, 3, side, side)] + ([torch.randn(2, 3, side // 2, side // 2)] if name == "mini_nested" else [])
+    it = iter(draws)
     pipe.train()
-    loss = pipe.get_loss(smp, time=None, noise_fn=lambda like: next(it).to(like.device)) if False else None
-    # get_eps_time draws randint on the images' device in the reference; replay it on CPU by passing explicit values
-    it = iter(noise)
-
-    class _Fixed:
-        pass
-
-    sampler = pipe.sampler
-    orig = sampler.get_eps_time
-
-    def fixed_eps_time(images, t=None, noise_fn=None):
-        tt = time.to(images.device)
-        return next(it).to(images.device), sampler.read_gamma(tt + 1), sampler.read_gamma(tt), sampler.vdm_loss_weights[tt + 1], tt
-
-    sampler.get_eps_time = fixed_eps_time
-    try:
-        loss = pipe.get_loss(smp, noise_fn=lambda like: next(it).to(like.device))[0]
-    finally:
-        sampler.get_eps_time = orig
+    loss = pipe.get_loss(smp, time=time.cuda(), noise_fn=lambda like: next(it).to(like.device))[0]
     assert O.rel_l2(loss.float().cpu(), gold["loss"]) < 1e-3
