@@ -18,6 +18,8 @@
 // register-staged global->LDS with the next tile's loads in flight during the
 // MFMA phase.  Operands are fed to MFMA swapped (D^T = W * A^T) so every lane
 // ends up with 4 consecutive output channels of one pixel -> vector stores.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mdm {
@@ -42,14 +44,20 @@ enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };
 // 16-byte-aligned zeros in device memory: the source of every out-of-range LDS-DMA chunk
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[4] = {};
 
-template <typename T, int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
+// NSTAGE = 2: 4-wave block, next tile's DMA overlaps this tile's MFMAs, __syncthreads() drains it (vmcnt(0)).
+// NSTAGE = 3: 8-wave block (256-row tile), DMA runs TWO tiles ahead; a counted s_waitcnt vmcnt(loads per tile) +
+//             raw s_barrier retires only the tile needed next, so loads stay in flight across the barrier
+//             (cdna_hip_programming.md section 5, "Pipelining across barriers").
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(ConvArgs p) {
   constexpr int EPV = Tr<T>::EPV, BK = Tr<T>::BK, KSTEPS = Tr<T>::KSTEPS;
+  constexpr int NT_ = WM * WN * 64;                  // threads per block
+  constexpr int RPP = NT_ / 8;                       // tile rows staged per pass (8 chunk lanes per row)
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MT = TM / 16, NT = TN / 16;
-  constexpr int AJ = BM / 32, BJ = BN / 32;
+  constexpr int AJ = BM / RPP, BJ = BN / RPP;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  static_assert(WM * WN == 4, "4 waves");
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   int a_oh[AJ], a_ow[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int m = m0 + lrow + 32 * j;
+    const int m = m0 + lrow + RPP * j;
     if (m < p.M) {
       if (MODE == MODE_1x1) {
         a_pix[j] = m; a_oh[j] = 0; a_ow[j] = 0;
@@ -117,13 +125,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
         off = (size_t)(a_pix[j] + ih * p.W + iw) * p.Cin + cin;                                           \
       }                                                                                                   \
       const T* src = v ? X + off : reinterpret_cast<const T*>(g_zero_page);                               \
-      MDM_GLDS(src, (stage) + j * 4096 + wave_lds);                                                       \
+      MDM_GLDS(src, (stage) + j * (RPP * 128) + wave_lds);                                                \
     }                                                                                                     \
     _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                                      \
-      const int n = n0 + lrow + 32 * j;                                                                   \
+      const int n = n0 + lrow + RPP * j;                                                                  \
       const bool v = kvalid && n < p.Cout;                                                                \
       const T* src = v ? Wp + (size_t)n * p.K + kcur : reinterpret_cast<const T*>(g_zero_page);           \
-      MDM_GLDS(src, (stage) + A_BYTES + j * 4096 + wave_lds);                                             \
+      MDM_GLDS(src, (stage) + A_BYTES + j * (RPP * 128) + wave_lds);                                      \
     }                                                                                                     \
     kcur += BK;                                                                                           \
     if (MODE != MODE_1x1) {                                                                               \
@@ -139,28 +147,47 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = (p.K + BK - 1) / BK;
-  MDM_STAGE_TILE(smem);
-  __syncthreads();
-  for (int kt = 0; kt < ntiles; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE;
-    const bool more = kt + 1 < ntiles;
-    if (more) MDM_STAGE_TILE(smem + ((kt + 1) & 1) * STAGE);
-    const char* As = cur;
-    const char* Bs = cur + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      Frag<T> af[MT], bfr[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) load_frag<T>(af[i], As, wm * TM + i * 16 + l16, ks, quad);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) load_frag<T>(bfr[j], Bs, wn * TN + j * 16 + l16, ks, quad);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
-    }
-    __syncthreads();   // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
+#define MDM_COMPUTE_TILE(cur)                                                                             \
+  {                                                                                                       \
+    const char* As = (cur);                                                                               \
+    const char* Bs = (cur) + A_BYTES;                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                               \
+      Frag<T> af[MT], bfr[NT];                                                                            \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) load_frag<T>(af[i], As, wm * TM + i * 16 + l16, ks, quad);   \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) load_frag<T>(bfr[j], Bs, wn * TN + j * 16 + l16, ks, quad);  \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                      \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);                   \
+    }                                                                                                     \
   }
+  if constexpr (NSTAGE == 2) {
+    MDM_STAGE_TILE(smem);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+      char* cur = smem + (kt & 1) * STAGE;
+      if (kt + 1 < ntiles) MDM_STAGE_TILE(smem + ((kt + 1) & 1) * STAGE);
+      MDM_COMPUTE_TILE(cur);
+      __syncthreads();   // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
+    }
+  } else {
+    // ring of 3 buffers, DMA two tiles ahead
+    MDM_STAGE_TILE(smem);
+    if (ntiles > 1) MDM_STAGE_TILE(smem + STAGE);
+    int cur_i = 0;
+    for (int kt = 0; kt < ntiles; ++kt) {
+      // retire tile kt (issued two iterations ago); tile kt+1 (AJ+BJ loads per lane) may stay in flight
+      if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AJ + BJ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done reading tile kt-1
+      if (kt + 2 < ntiles) {
+        int nxt = cur_i + 2; if (nxt >= 3) nxt -= 3;
+        MDM_STAGE_TILE(smem + nxt * STAGE);
+      }
+      MDM_COMPUTE_TILE(smem + cur_i * STAGE);
+      if (++cur_i == 3) cur_i = 0;
+    }
+    __syncthreads();   // LDS is reused by the epilogue
+  }
+#undef MDM_COMPUTE_TILE
 #undef MDM_STAGE_TILE
 #undef MDM_GLDS
 
@@ -172,8 +199,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   T* __restrict__ Ypre = reinterpret_cast<T*>(p.ypre);
   const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
   const T* __restrict__ AUX = reinterpret_cast<const T*>(p.aux);
-  constexpr int PITCH = sizeof(T) == 2 ? BN * 2 + 16 : BN * 4;   // bytes per staged row
-  static_assert(BM * PITCH <= 2 * STAGE, "output tile must fit the k-loop LDS");
+  constexpr int PITCH = (sizeof(T) == 2 && BM * (BN * 2 + 16) <= NSTAGE * STAGE) ? BN * 2 + 16 : BN * (int)sizeof(T);   // bytes per staged row
+  static_assert(BM * PITCH <= NSTAGE * STAGE, "output tile must fit the k-loop LDS");
   constexpr int OCH = BN / EPV;                                    // 16-byte chunks per staged row
   if ((p.Cout % EPV) == 0) {
     const int first_pass = (p.act == 1 && Ypre) ? 0 : 1;
@@ -217,7 +244,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
       }
       __syncthreads();
       T* __restrict__ OUT = pass == 0 ? Ypre : Y;
-      for (int idx = tid; idx < BM * OCH; idx += 256) {
+      for (int idx = tid; idx < BM * OCH; idx += NT_) {
         const int row = idx / OCH, ch = idx - row * OCH;
         const int m = m0 + row, n = n0 + ch * EPV;
         if (m < p.M && n < p.Cout)
@@ -743,25 +770,44 @@ using namespace mdm;
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int MODE>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int NSTAGE>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
-  constexpr int smem = 2 * (BM + BN) * 128;
-  auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, MODE>;
+  constexpr int smem = NSTAGE * (BM + BN) * 128;
+  auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, MODE, NSTAGE>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_done = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), smem, st, a);
   MDM_LAUNCH_STATUS();
 }
 
+static int g_big_tile = -1;   // MDM_HIP_BIGTILE=0 forces the 128x128 kernel (A/B testing)
+
 template <typename T, int MODE>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
-  if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE>(a, st);
-  if (a.Cout <= 64) return launch_conv_cfg<T, 128, 64, 2, 2, MODE>(a, st);
-  return launch_conv_cfg<T, 128, 128, 2, 2, MODE>(a, st);
+  if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE, 2>(a, st);
+  if (a.Cout <= 64) return launch_conv_cfg<T, 128, 64, 2, 2, MODE, 2>(a, st);
+  if (g_big_tile < 0) {
+    const char* e = getenv("MDM_HIP_BIGTILE");
+    g_big_tile = e ? atoi(e) : 2;
+  }
+  // Tile choice (measured, tools/kbench.py): the 256x256 8-wave tile (wave tile 128x64) halves the LDS bytes per
+  // FLOP of the 128x128 one and wins 10-17 % when it fills the 256 CUs in whole waves; with few or ragged tile
+  // counts the 128x128 kernel (2 blocks / CU) wins.  MDM_HIP_BIGTILE: 0 = always 128x128, 1 = 256x128 3-stage
+  // (counted vmcnt; kept for A/B), 2 = default rule.
+  const long big_tiles = (long)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
+  const long huge_tiles = (long)((a.M + 255) / 256) * ((a.Cout + 255) / 256);
+  if constexpr (sizeof(T) == 2) {
+    if (g_big_tile == 2 && huge_tiles >= 256) {
+      const long waves = (huge_tiles + 255) / 256;
+      if (huge_tiles * 5 >= waves * 256 * 4) return launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2>(a, st);
+    }
+  }
+  if (g_big_tile == 1 && big_tiles >= 256) return launch_conv_cfg<T, 256, 128, 4, 2, MODE, 3>(a, st);
+  return launch_conv_cfg<T, 128, 128, 2, 2, MODE, 2>(a, st);
 }
 
 template <typename T>

@@ -50,6 +50,9 @@ def nchw(t_nhwc):
         (1, 7, 5, 24, 8, 3, 1),         # small N config
         (2, 32, 32, 32, 32, 3, 1),
         (2, 12, 12, 136, 264, 3, 1),    # Cin not a multiple of the k-tile
+        (8, 121, 119, 40, 136, 3, 1),   # 450 tiles of 256x256: the 8-wave big-tile kernel, ragged M / N / K
+        (4, 128, 128, 72, 200, 1, 1),   # same, 1x1, exactly one wave of tiles
+        (4, 256, 256, 16, 72, 3, 2),    # same, stride 2 (forward) + transposed gradient
     ],
 )
 def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):

@@ -46,7 +46,10 @@ def timeit(fn, iters=10):
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
-    for name, H, cin, cout, ks, stride in SHAPES:
+    only = os.environ.get("KB_ONLY")
+    for idx, (name, H, cin, cout, ks, stride) in enumerate(SHAPES):
+        if only is not None and idx != int(only):
+            continue
         x = torch.randn(B, H, H, cin, device=dev).to(DT)
         w = (torch.randn(cout, cin, ks, ks, device=dev) / (cin * ks * ks) ** 0.5)
         b = torch.randn(cout, device=dev)
