@@ -525,16 +525,84 @@ __device__ __forceinline__ void load_frags_tr(Frag<bf16> (&af)[4], Frag<bf16> (&
   }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs p) {
+// 256 x 256 output tile, 8 waves (2 over Cout x 4 over k), wave tile 128 x 64: the same LDS-DMA + transpose-read
+// scheme with half the LDS bytes per FLOP of the 128 x 128 kernel.  Natural-layout rows are 512 bytes here.
+template <int OFF>
+__device__ __forceinline__ void load_frags_tr_big(Frag<bf16> (&af)[8], Frag<bf16> (&bf_)[4], const unsigned (&a)[8],
+                                                  const unsigned (&b)[4]) {
+  // OFF = byte offset of the k-step; the upper 4 pixel rows of a fragment are +4 * 512 = 2048 bytes
+  s16x4 r[24];
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %1, %16 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %2, %17 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %3, %17 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %4, %18 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %5, %18 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %6, %19 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %7, %19 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %8, %20 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %9, %20 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %10, %21 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %11, %21 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %12, %22 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %13, %22 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %14, %23 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %15, %23 offset:%25"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+        "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "i"(OFF), "i"(OFF + 2048)
+      : "memory");
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %2, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %4, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %6, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13"
+      : "=&v"(r[16]), "=&v"(r[17]), "=&v"(r[18]), "=&v"(r[19]), "=&v"(r[20]), "=&v"(r[21]), "=&v"(r[22]), "=&v"(r[23])
+      : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "i"(OFF), "i"(OFF + 2048)
+      : "memory");
+  // one wait for all 24 reads; every destination is named so nothing is consumed (or moved) before it
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                 "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]),
+                 "+v"(r[16]), "+v"(r[17]), "+v"(r[18]), "+v"(r[19]), "+v"(r[20]), "+v"(r[21]), "+v"(r[22]), "+v"(r[23])
+               :
+               : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    s16x8 v = {r[2 * i][0], r[2 * i][1], r[2 * i][2], r[2 * i][3], r[2 * i + 1][0], r[2 * i + 1][1], r[2 * i + 1][2], r[2 * i + 1][3]};
+    af[i].v = *reinterpret_cast<bf16x8*>(&v);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s16x8 v = {r[16 + 2 * i][0], r[16 + 2 * i][1], r[16 + 2 * i][2], r[16 + 2 * i][3], r[17 + 2 * i][0], r[17 + 2 * i][1], r[17 + 2 * i][2], r[17 + 2 * i][3]};
+    bf_[i].v = *reinterpret_cast<bf16x8*>(&v);
+  }
+}
+
+// BIG = 0: 128 x 128 tile, 4 waves (wave tile 64 x 64), 256-byte rows, 2 blocks / CU
+// BIG = 1: 256 x 256 tile, 8 waves (wave tile 128 x 64), 512-byte rows, 1 block / CU
+template <int MODE, int BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArgs p) {
   typedef bf16 T;
   constexpr int EPV = 8, BKM = 64;
-  constexpr int BM = 128, BN = 128, TM = 64, TN = 64, MT = 4, NT = 4;
-  constexpr int A_BYTES = BKM * 256, STAGE = 2 * A_BYTES;   // 16 KB per operand
+  constexpr int NTHR = BIG ? 512 : 256;
+  constexpr int BM = BIG ? 256 : 128, BN = BM;                 // BM over Cout, BN over k
+  constexpr int TM = BIG ? 128 : 64, TN = 64, MT = TM / 16, NT = 4;
+  constexpr int ROWB = BM * 2;                                 // bytes per natural-layout row (256 / 512)
+  constexpr int CPRW = ROWB / 16;                              // 16-byte chunks per row (16 / 32)
+  constexpr int RPP = NTHR / CPRW;                             // rows staged per pass (16)
+  constexpr int A_BYTES = BKM * ROWB, STAGE = 2 * A_BYTES;     // 16 / 32 KB per operand
+  constexpr int NWN = BIG ? 4 : 2;                             // waves across k
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int quad = lane >> 4, l16 = lane & 15;
 
   const int tiles_k = (p.K + BN - 1) / BN;
@@ -548,11 +616,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs p) {
   const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
 
-  // staging role of this thread: physical 16-byte slot `ps` of rows (j*16 + wave*4 + quad), j = 0..3
-  const int ps = l16;
-  const int srow = wave * 4 + quad;                          // + 16 j
-  const int lc = ((((ps >> 1) ^ tr_swz(srow)) << 1) | (ps & 1));   // logical chunk (same for every j: 16 j keeps bits 0-1,3... see note)
-  // note: tr_swz uses row bits 0,1,3; rows srow + 16 j share them, so one logical chunk serves all four passes
+  // staging role: physical 16-byte slot `ps` of rows srow + RPP * j (j = 0..3); RPP = 16 keeps row bits 0,1,3 that
+  // feed tr_swz unchanged across passes, so one logical chunk (hence one (tap, cin)) serves all four passes
+  const int ps = tid % CPRW;
+  const int srow = tid / CPRW;
+  const int lc = ((((ps >> 1) ^ tr_swz(srow)) << 1) | (ps & 1));
   const int a_col = n0 + lc * EPV;
   const bool a_ok = a_col < p.Cout;
   const int kk = k0 + lc * EPV;
@@ -566,11 +634,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs p) {
   const int mt_total = (p.M + BKM - 1) / BKM;
   const int mt_end = min(mt_total, mt_begin + p.mtiles_per_split);
 
-  // pixel coordinates of the 4 staged rows of the next tile to be issued
   int pn[4], poh[4], pow_[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int m = mt_begin * BKM + j * 16 + srow;
+    const int m = mt_begin * BKM + j * RPP + srow;
     if (MODE != MODE_1x1) {
       const int hw = p.Ho * p.Wo;
       pn[j] = m / hw;
@@ -586,10 +653,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs p) {
 #define MDM_WG_STAGE(stage)                                                                               \
   {                                                                                                       \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
-      const int m = m_next + j * 16 + srow;                                                               \
+      const int m = m_next + j * RPP + srow;                                                              \
       const bool mv = m < p.M;                                                                            \
       const T* sa = (mv && a_ok) ? DY + (size_t)m * p.Cout + a_col : reinterpret_cast<const T*>(g_zero_page); \
-      MDM_GLDS(sa, (stage) + j * 4096 + wave_lds);                                                        \
+      MDM_GLDS(sa, (stage) + j * (RPP * ROWB) + wave_lds);                                                \
       bool v = mv && b_ok;                                                                                \
       size_t off;                                                                                         \
       if (MODE == MODE_1x1) {                                                                             \
@@ -603,7 +670,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs p) {
         while (poh[j] >= p.Ho) { poh[j] -= p.Ho; ++pn[j]; }                                               \
       }                                                                                                   \
       const T* sb = v ? X + off : reinterpret_cast<const T*>(g_zero_page);                                \
-      MDM_GLDS(sb, (stage) + A_BYTES + j * 4096 + wave_lds);                                              \
+      MDM_GLDS(sb, (stage) + A_BYTES + j * (RPP * ROWB) + wave_lds);                                      \
     }                                                                                                     \
     m_next += BKM;                                                                                        \
   }
@@ -616,16 +683,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs p) {
 
   // per-lane LDS byte addresses of the transpose reads: reduction row quad*8 + (l16>>2) (+4 for the upper half,
   // +32 rows per k-step: immediates), 16-channel column tile `c`, 4-element segment l16 & 3
-  unsigned fa[4], fb[4];
+  unsigned fa[MT], fb[NT];
   {
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int r0 = quad * 8 + (l16 >> 2);
     const int fsw = (l16 >> 2) | ((quad & 1) << 2);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      fa[c] = smem_base + r0 * 256 + (((wm * 4 + c) ^ fsw) << 5) + ((l16 & 3) << 3);
-      fb[c] = smem_base + A_BYTES + r0 * 256 + (((wn * 4 + c) ^ fsw) << 5) + ((l16 & 3) << 3);
-    }
+    for (int c = 0; c < MT; ++c) fa[c] = smem_base + r0 * ROWB + (((wm * MT + c) ^ fsw) << 5) + ((l16 & 3) << 3);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) fb[c] = smem_base + A_BYTES + r0 * ROWB + (((wn * NT + c) ^ fsw) << 5) + ((l16 & 3) << 3);
   }
 
   if (mt_begin < mt_end) {
@@ -633,24 +699,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs p) {
     __syncthreads();
     for (int mt = mt_begin; mt < mt_end; ++mt) {
       const int it = mt - mt_begin;
-      char* cur = smem + (it & 1) * STAGE;
       if (mt + 1 < mt_end) MDM_WG_STAGE(smem + ((it + 1) & 1) * STAGE);
       const unsigned so = (unsigned)((it & 1) * STAGE);
-      {
-        Frag<T> af[MT], bfr[NT];
-        load_frags_tr<0>(af, bfr, fa[0] + so, fa[1] + so, fa[2] + so, fa[3] + so, fb[0] + so, fb[1] + so, fb[2] + so, fb[3] + so);
+      if constexpr (BIG) {
+        unsigned a8[8], b4[4];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int c = 0; c < 8; ++c) a8[c] = fa[c] + so;
 #pragma unroll
-          for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
-      }
-      {
-        Frag<T> af[MT], bfr[NT];
-        load_frags_tr<8192>(af, bfr, fa[0] + so, fa[1] + so, fa[2] + so, fa[3] + so, fb[0] + so, fb[1] + so, fb[2] + so, fb[3] + so);
+        for (int c = 0; c < 4; ++c) b4[c] = fb[c] + so;
+        {
+          Frag<T> af[8], bfr[4];
+          load_frags_tr_big<0>(af, bfr, a8, b4);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+          for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
+            for (int j = 0; j < 4; ++j) mma16(acc[i][j], bfr[j], af[i]);
+        }
+        {
+          Frag<T> af[8], bfr[4];
+          load_frags_tr_big<32 * ROWB>(af, bfr, a8, b4);
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16(acc[i][j], bfr[j], af[i]);
+        }
+      } else {
+        {
+          Frag<T> af[4], bfr[4];
+          load_frags_tr<0>(af, bfr, fa[0] + so, fa[1] + so, fa[2] + so, fa[3] + so, fb[0] + so, fb[1] + so, fb[2] + so, fb[3] + so);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16(acc[i][j], bfr[j], af[i]);
+        }
+        {
+          Frag<T> af[4], bfr[4];
+          load_frags_tr<8192>(af, bfr, fa[0] + so, fa[1] + so, fa[2] + so, fa[3] + so, fb[0] + so, fb[1] + so, fb[2] + so, fb[3] + so);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16(acc[i][j], bfr[j], af[i]);
+        }
       }
       __syncthreads();
     }
@@ -840,12 +929,26 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
 }
 
 // workspace size (bytes) the caller must provide to mdm_conv_wgrad
+static int g_wgrad_big = -1;   // MDM_HIP_WGRAD_BIG=0 disables the 256x256 wgrad tile (A/B testing)
+
+// tile edge used for a problem: 256 for the bf16 8-wave kernel when both output dims reach it and the reduction
+// is long enough to amortise its larger prologue (measured: 3x3 layers +15-35 %, 1x1 layers at M = 16384 -25 %)
+static int wgrad_tile(int M, int Cout, int K, int dtype) {
+  if (g_wgrad_big < 0) {
+    const char* e = getenv("MDM_HIP_WGRAD_BIG");
+    g_wgrad_big = e ? atoi(e) : 1;
+  }
+  return (dtype == DT_BF16 && g_wgrad_big && Cout >= 256 && K >= 256 && (K >= 2304 || M >= 65536)) ? 256 : 128;
+}
+
 extern "C" int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes) {
   MDM_CHECK_ARG(splits_out && ws_bytes);
   const int bkm = dtype == DT_F32 ? 32 : 64;
-  const int tiles = ((Cout + 127) / 128) * ((K + 127) / 128);
+  const int te = wgrad_tile(M, Cout, K, dtype);
+  const int tiles = ((Cout + te - 1) / te) * ((K + te - 1) / te);
   const int mt_total = (M + bkm - 1) / bkm;
-  int splits = (1024 + tiles - 1) / tiles;           // aim at ~4 workgroups per CU
+  const int target = te == 256 ? 512 : 1024;           // workgroups: 1 (256^2) or 2 (128^2) resident per CU
+  int splits = (target + tiles - 1) / tiles;
   if (splits > mt_total) splits = mt_total;
   const int max_by_work = (mt_total + 7) / 8;          // >= 8 reduction tiles per split
   if (splits > max_by_work) splits = max_by_work;
@@ -855,6 +958,11 @@ extern "C" int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* split
   *splits_out = splits;
   *ws_bytes = (size_t)splits * Cout * K * sizeof(float);
   return 0;
+}
+
+template <typename K>
+static void wgrad_set_smem(K kern, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, float* ws, int N, int H, int W,
@@ -874,24 +982,30 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, flo
   const int bkm = dtype == DT_F32 ? 32 : 64;
   const int mt_total = (a.M + bkm - 1) / bkm;
   a.mtiles_per_split = (mt_total + a.splits - 1) / a.splits;
-  const int tiles = ((Cout + 127) / 128) * ((a.K + 127) / 128);
+  const int te = wgrad_tile(a.M, Cout, a.K, dtype);
+  const int tiles = ((Cout + te - 1) / te) * ((a.K + te - 1) / te);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  constexpr int smem = 4 * 128 * 128;
+  constexpr int smem = 4 * 128 * 128, smem_big = 4 * 64 * 512;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<float, MODE_1x1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<float, MODE_3x3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tr_kernel<MODE_1x1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tr_kernel<MODE_3x3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    wgrad_set_smem(conv_wgrad_kernel<float, MODE_1x1>, smem);
+    wgrad_set_smem(conv_wgrad_kernel<float, MODE_3x3>, smem);
+    wgrad_set_smem(conv_wgrad_tr_kernel<MODE_1x1, 0>, smem);
+    wgrad_set_smem(conv_wgrad_tr_kernel<MODE_3x3, 0>, smem);
+    wgrad_set_smem(conv_wgrad_tr_kernel<MODE_1x1, 1>, smem_big);
+    wgrad_set_smem(conv_wgrad_tr_kernel<MODE_3x3, 1>, smem_big);
     attr_done = true;
   }
-  dim3 grid(tiles * a.splits), block(256);
+  dim3 grid(tiles * a.splits);
   if (dtype == DT_F32) {
-    if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_kernel<float, MODE_1x1>), grid, block, smem, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<float, MODE_3x3>), grid, block, smem, st, a);
+    if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_kernel<float, MODE_1x1>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<float, MODE_3x3>), grid, dim3(256), smem, st, a);
+  } else if (te == 256) {
+    if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_1x1, 1>), grid, dim3(512), smem_big, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_3x3, 1>), grid, dim3(512), smem_big, st, a);
   } else {
-    if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_1x1>), grid, block, smem, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_3x3>), grid, block, smem, st, a);
+    if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_1x1, 0>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_3x3, 0>), grid, dim3(256), smem, st, a);
   }
   const size_t total = (size_t)Cout * a.K;
   const int rb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);

@@ -53,6 +53,8 @@ def nchw(t_nhwc):
         (8, 121, 119, 40, 136, 3, 1),   # 450 tiles of 256x256: the 8-wave big-tile kernel, ragged M / N / K
         (4, 128, 128, 72, 200, 1, 1),   # same, 1x1, exactly one wave of tiles
         (4, 256, 256, 16, 72, 3, 2),    # same, stride 2 (forward) + transposed gradient
+        (3, 24, 20, 264, 328, 3, 1),    # Cout >= 256 and K >= 256: the 256x256 transpose-read wgrad tile, ragged
+        (2, 16, 16, 512, 256, 1, 1),    # same, 1x1
     ],
 )
 def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
