@@ -40,7 +40,10 @@ const char* mdm_last_error(void);
  * models/nested_unet.py:109-128) and nn.Linear (unet.py:206, 264, 605-609, 625-626, 763).
  *
  * mdm_pack_weight: reference layout (Cout, Cin, k, k) fp32  ->  w_fwd [Cout][k*k][Cin_pad] and
- *   (optional) w_dgrad [Cin][k*k flipped][Cout_pad], both of `dtype`.
+ *   (optional) w_dgrad [Cin][k*k flipped][Cout_pad], both of `dtype`.  kblock_* != 0 selects the
+ *   channel-block-major reduction order for a 3x3 pack (k = (c / B) * 9B + tap * B + c % B, B = 64 for bf16,
+ *   32 for fp32; needs C % B == 0): the 9 taps of a channel block become consecutive k-tiles, which keeps the
+ *   shifted re-reads of the activation in L1/L2.  The same value must be passed to mdm_conv_fwd as `kblock`.
  * mdm_conv_fwd:  y = epilogue(conv(x, w_packed)).  epilogue = +bias, act, +res (in this order);
  *   act == MDM_ACT_GELU writes the pre-activation to y_pre when non-null;
  *   act == MDM_ACT_DGELU_AUX multiplies by gelu'(aux) (backward through the FFN GELU, unet.py:270).
@@ -50,10 +53,10 @@ const char* mdm_last_error(void);
  * mdm_colsum: out[c] = sum_m x[m, c]  (bias gradients); ws from mdm_colsum_plan.
  */
 int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int ksize, int Cin_pad,
-                    int Cout_pad, int dtype, void* stream);
+                    int Cout_pad, int kblock_fwd, int kblock_dgrad, int dtype, void* stream);
 int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const void* res, const void* aux, void* y,
                  void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride,
-                 int transposed, int act, int dtype, void* stream);
+                 int transposed, int act, int kblock, int dtype, void* stream);
 int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes);
 int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, float* ws, int N, int H, int W, int Cin, int Ho,
                    int Wo, int Cout, int ksize, int stride, int dtype, void* stream);

@@ -37,6 +37,8 @@ struct ConvArgs {
   int stride;
   int M, K;
   int act;            // 0 none, 1 y=gelu(v), 2 y=v*gelu'(aux)
+  int kblk;           // 3x3 k-order: 0 = tap-major (k = tap*Cin + cin); B = channel-block-major,
+                      // k = (cin / B) * 9 * B + tap * B + cin % B with B = the k-tile (64 bf16 / 32 fp32)
 };
 
 enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };
@@ -48,7 +50,11 @@ __device__ __attribute__((aligned(16))) uint4 g_zero_page[4] = {};
 // NSTAGE = 3: 8-wave block (256-row tile), DMA runs TWO tiles ahead; a counted s_waitcnt vmcnt(loads per tile) +
 //             raw s_barrier retires only the tile needed next, so loads stay in flight across the barrier
 //             (cdna_hip_programming.md section 5, "Pipelining across barriers").
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int NSTAGE>
+// PP (ping-pong, 8-wave tiles only): the two waves that share a SIMD (w and w + 4) run one segment apart --
+//     while one issues its 32 MFMAs of a k-step the other does its LDS fragment reads / next-tile DMA -- with a
+//     raw s_barrier after every segment, so the matrix pipe always has exactly one wave feeding it instead of
+//     both waves loading together and then fighting for the pipe.
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int NSTAGE, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(ConvArgs p) {
   constexpr int EPV = Tr<T>::EPV, BK = Tr<T>::BK, KSTEPS = Tr<T>::KSTEPS;
   constexpr int NT_ = WM * WN * 64;                  // threads per block
@@ -94,7 +100,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(ConvArgs p) {
   }
   int kcur = lchunk * EPV;  // this thread's k within the current k-tile (global k)
   int tap = 0, cin = kcur;
-  if (MODE != MODE_1x1) { tap = kcur / p.Cin; cin = kcur - tap * p.Cin; }
+  // channel-block-major order (kblk): one k-tile = one (64-channel block, tap); the 9 taps of a channel block are
+  // 9 consecutive k-tiles, so the shifted re-reads of the same activation lines hit L1/L2 instead of coming back
+  // from the Infinity Cache a whole Cin-sweep later (tap-major order re-reads each line after Cin/64 k-tiles)
+  const bool kblk = MODE != MODE_1x1 && p.kblk != 0;
+  if (MODE != MODE_1x1 && !kblk) { tap = kcur / p.Cin; cin = kcur - tap * p.Cin; }
 
   // Global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  The DMA writes
   // lane-linear (wave base + lane * 16), i.e. thread (row = tid >> 3, slot = tid & 7) of pass j fills physical
@@ -135,8 +145,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(ConvArgs p) {
     }                                                                                                     \
     kcur += BK;                                                                                           \
     if (MODE != MODE_1x1) {                                                                               \
-      cin += BK;                                                                                          \
-      while (cin >= p.Cin) { cin -= p.Cin; ++tap; }                                                       \
+      if (kblk) {                                                                                         \
+        if (++tap == 9) { tap = 0; cin += BK; }                                                           \
+      } else {                                                                                            \
+        cin += BK;                                                                                        \
+        while (cin >= p.Cin) { cin -= p.Cin; ++tap; }                                                     \
+      }                                                                                                   \
     }                                                                                                     \
   }
 
@@ -159,7 +173,62 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(ConvArgs p) {
         _Pragma("unroll") for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);                   \
     }                                                                                                     \
   }
-  if constexpr (NSTAGE == 2) {
+  if constexpr (NSTAGE == 2 && PP) {
+    static_assert(WM * WN == 8 && KSTEPS == 2, "ping-pong schedule: 8 waves, two k-steps per tile");
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    MDM_STAGE_TILE(smem);
+    __syncthreads();                                  // tile 0 landed
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one segment behind group 0
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const char* As = smem + (kt & 1) * STAGE;
+      const char* Bs = As + A_BYTES;
+      Frag<T> af[MT], bfr[NT];
+      // ---- segment L0: next tile's DMA + fragment reads of k-step 0
+      if (kt + 1 < ntiles) MDM_STAGE_TILE(smem + ((kt + 1) & 1) * STAGE);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) load_frag<T>(af[i], As, wm * TM + i * 16 + l16, 0, quad);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) load_frag<T>(bfr[j], Bs, wn * TN + j * 16 + l16, 0, quad);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- segment M0
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- segment L1: fragment reads of k-step 1
+#pragma unroll
+      for (int i = 0; i < MT; ++i) load_frag<T>(af[i], As, wm * TM + i * 16 + l16, 1, quad);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) load_frag<T>(bfr[j], Bs, wn * TN + j * 16 + l16, 1, quad);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // group 1's L1 is the segment right before group 0 reads the next tile: its DMA must have landed by now
+      if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- segment M1
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
+      __builtin_amdgcn_s_setprio(0);
+      if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's extra leading barrier
+    __syncthreads();                                  // LDS is reused by the epilogue
+  } else if constexpr (NSTAGE == 2) {
     MDM_STAGE_TILE(smem);
     __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -789,21 +858,28 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 // Cin_pad >= Cin lets the 3-channel stem be zero-padded to a chunk multiple.
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
-                                   int Cout, int Cin, int taps, int Cin_pad, int Cout_pad) {
-  const size_t total_f = (size_t)Cout * taps * Cin_pad;
-  const size_t total_d = wd ? (size_t)Cin * taps * Cout_pad : 0;
+                                   int Cout, int Cin, int taps, int Cin_pad, int Cout_pad, int kbf, int kbd) {
+  // wf[o][kpos], kpos over (tap, cin) in tap-major (kbf == 0) or channel-block-major (kbf = block) order;
+  // wd[i][kpos], kpos over (flipped tap, cout) likewise with kbd.
+  const size_t Kf = (size_t)taps * Cin_pad, Kd = (size_t)taps * Cout_pad;
+  const size_t total_f = (size_t)Cout * Kf;
+  const size_t total_d = wd ? (size_t)Cin * Kd : 0;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_f + total_d;
        idx += (size_t)gridDim.x * blockDim.x) {
     if (idx < total_f) {
-      const int i = (int)(idx % Cin_pad);
-      const size_t r = idx / Cin_pad;
-      const int tp = (int)(r % taps), o = (int)(r / taps);
+      const int o = (int)(idx / Kf);
+      const int kpos = (int)(idx - (size_t)o * Kf);
+      int tp, i;
+      if (kbf) { const int cb = kpos / (taps * kbf), r = kpos - cb * taps * kbf; tp = r / kbf; i = cb * kbf + (r - tp * kbf); }
+      else { tp = kpos / Cin_pad; i = kpos - tp * Cin_pad; }
       wf[idx] = from_f32<T>(i < Cin ? w[((size_t)o * Cin + i) * taps + tp] : 0.f);
     } else {
       const size_t d = idx - total_f;
-      const int o = (int)(d % Cout_pad);
-      const size_t r = d / Cout_pad;
-      const int tp = (int)(r % taps), i = (int)(r / taps);
+      const int i = (int)(d / Kd);
+      const int kpos = (int)(d - (size_t)i * Kd);
+      int tp, o;
+      if (kbd) { const int ob = kpos / (taps * kbd), r = kpos - ob * taps * kbd; tp = r / kbd; o = ob * kbd + (r - tp * kbd); }
+      else { tp = kpos / Cout_pad; o = kpos - tp * Cout_pad; }
       wd[d] = from_f32<T>(o < Cout ? w[((size_t)o * Cin + i) * taps + (taps - 1 - tp)] : 0.f);
     }
   }
@@ -859,10 +935,10 @@ using namespace mdm;
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int NSTAGE>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int NSTAGE, bool PP = false>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
   constexpr int smem = NSTAGE * (BM + BN) * 128;
-  auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, MODE, NSTAGE>;
+  auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, MODE, NSTAGE, PP>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -892,7 +968,11 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if (g_big_tile == 2 && huge_tiles >= 256) {
       const long waves = (huge_tiles + 255) / 256;
-      if (huge_tiles * 5 >= waves * 256 * 4) return launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2>(a, st);
+      if (huge_tiles * 5 >= waves * 256 * 4) {
+        static int pp = -1;
+        if (pp < 0) { const char* e = getenv("MDM_HIP_PINGPONG"); pp = e ? atoi(e) : 0; }   // measured equal to the plain schedule; off by default
+        return pp ? launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2, true>(a, st) : launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2, false>(a, st);
+      }
     }
   }
   if (g_big_tile == 1 && big_tiles >= 256) return launch_conv_cfg<T, 256, 128, 4, 2, MODE, 3>(a, st);
@@ -908,7 +988,8 @@ static int launch_conv_t(const ConvArgs& a, int ks, int transposed, hipStream_t 
 
 extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const void* res,
                             const void* aux, void* y, void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo,
-                            int Cout, int ksize, int stride, int transposed, int act, int dtype, void* stream) {
+                            int Cout, int ksize, int stride, int transposed, int act, int kblock, int dtype,
+                            void* stream) {
   MDM_CHECK_ARG(x && w_packed && y);
   MDM_CHECK_ARG(ksize == 1 || ksize == 3);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
@@ -924,6 +1005,9 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
   a.x = x; a.w = w_packed; a.bias = bias; a.res = res; a.aux = aux; a.y = y; a.ypre = y_pre;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.stride = stride;
   a.M = N * Ho * Wo; a.K = ksize * ksize * Cin; a.act = act;
+  const int bk = dtype == DT_F32 ? 32 : 64;
+  MDM_CHECK_ARG(kblock == 0 || (ksize == 3 && kblock == bk && Cin % bk == 0));
+  a.kblk = kblock;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return dtype == DT_F32 ? launch_conv_t<float>(a, ksize, transposed, st) : launch_conv_t<bf16>(a, ksize, transposed, st);
 }
@@ -1014,18 +1098,21 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, flo
 }
 
 extern "C" int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int ksize,
-                               int Cin_pad, int Cout_pad, int dtype, void* stream) {
+                               int Cin_pad, int Cout_pad, int kblock_fwd, int kblock_dgrad, int dtype,
+                               void* stream) {
   MDM_CHECK_ARG(w_oihw && w_fwd);
   MDM_CHECK_ARG(ksize == 1 || ksize == 3);
   MDM_CHECK_ARG(Cin_pad >= Cin && Cout_pad >= Cout);
+  MDM_CHECK_ARG(kblock_fwd == 0 || (ksize == 3 && Cin_pad % kblock_fwd == 0));
+  MDM_CHECK_ARG(kblock_dgrad == 0 || (ksize == 3 && Cout_pad % kblock_dgrad == 0));
   const int taps = ksize * ksize;
   const size_t total = (size_t)Cout * taps * Cin_pad + (w_dgrad ? (size_t)Cin * taps * Cout_pad : 0);
   const int nb = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DT_F32)
-    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(nb), dim3(256), 0, st, w_oihw, (float*)w_fwd, (float*)w_dgrad, Cout, Cin, taps, Cin_pad, Cout_pad);
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(nb), dim3(256), 0, st, w_oihw, (float*)w_fwd, (float*)w_dgrad, Cout, Cin, taps, Cin_pad, Cout_pad, kblock_fwd, kblock_dgrad);
   else if (dtype == DT_BF16)
-    hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(nb), dim3(256), 0, st, w_oihw, (bf16*)w_fwd, (bf16*)w_dgrad, Cout, Cin, taps, Cin_pad, Cout_pad);
+    hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(nb), dim3(256), 0, st, w_oihw, (bf16*)w_fwd, (bf16*)w_dgrad, Cout, Cin, taps, Cin_pad, Cout_pad, kblock_fwd, kblock_dgrad);
   else MDM_CHECK_ARG(false);
   MDM_LAUNCH_STATUS();
 }

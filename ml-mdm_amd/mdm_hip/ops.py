@@ -93,8 +93,13 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
     wd = torch.empty(cin * taps * cout_pad, dtype=dtype, device=weight.device) if need_d else None
     if cout_pad != cout:
         wf.zero_()
+    # 3x3: channel-block-major reduction order whenever the channel count is a multiple of the k-tile
+    bk = 32 if dtype == torch.float32 else 64
+    kbf = bk if (ks == 3 and cin_pad % bk == 0) else 0
+    kbd = bk if (ks == 3 and cout_pad % bk == 0) else 0
     _lib.check(
-        L.mdm_pack_weight(_p(w32), _p(wf), _p(wd), cout, cin, ks, cin_pad, cout_pad, F32 if dtype == torch.float32 else BF16, _stream()),
+        L.mdm_pack_weight(_p(w32), _p(wf), _p(wd), cout, cin, ks, cin_pad, cout_pad, kbf, kbd,
+                          F32 if dtype == torch.float32 else BF16, _stream()),
         "mdm_pack_weight",
     )
     bp = None
@@ -103,7 +108,7 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
         if cout_pad != cout:
             bp = torch.cat([bp, bp.new_zeros(cout_pad - cout)])
         bp = _c(bp)
-    val = (wf, wd, bp, cin_pad, cout_pad)
+    val = (wf, wd, bp, cin_pad, cout_pad, kbf, kbd)
     ent[key] = (ver, val)
     return val
 
@@ -160,11 +165,11 @@ def profile_end(peak_tflops):
 # --------------------------------------------------------------------------------------
 # raw launches
 # --------------------------------------------------------------------------------------
-def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, stride, transposed, act):
+def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, stride, transposed, act, kblk=0):
     def go():
         _lib.check(
             _lib.lib().mdm_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(aux), _p(y), _p(ypre), N, H, W, Cin, Ho, Wo, Cout,
-                                    ks, stride, transposed, act, _dt(x), _stream()),
+                                    ks, stride, transposed, act, kblk, _dt(x), _stream()),
             "mdm_conv_fwd",
         )
 
@@ -232,12 +237,12 @@ class ConvFn(torch.autograd.Function):
         x = _c(x)
         residual = _c(residual)
         ks = weight.shape[2] if weight.dim() == 4 else 1
-        wf, wd, bp, cin_pad, cout_pad = packed_weight(weight, bias, x.dtype)
+        wf, wd, bp, cin_pad, cout_pad, kbf, kbd = packed_weight(weight, bias, x.dtype)
         if x.shape[-1] != cin_pad:
             raise _lib.MdmHipError("conv input has %d channels, packed weight expects %d" % (x.shape[-1], cin_pad))
         N, H, W, Ho, Wo = _geom(x, ks, stride)
         y = torch.empty(_out_shape(x, Ho, Wo, cout_pad), dtype=x.dtype, device=x.device)
-        _conv_launch(x, wf, bp, residual, None, y, None, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, 0, 0)
+        _conv_launch(x, wf, bp, residual, None, y, None, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, 0, 0, kbf)
         ctx.save_for_backward(x, weight, bias)
         ctx.stride, ctx.ks = stride, ks
         ctx.has_res = residual is not None
@@ -248,7 +253,7 @@ class ConvFn(torch.autograd.Function):
         x, weight, bias = ctx.saved_tensors
         dy = _c(dy)
         ks, stride = ctx.ks, ctx.stride
-        wf, wd, bp, cin_pad, cout_pad = packed_weight(weight, bias, x.dtype)
+        wf, wd, bp, cin_pad, cout_pad, kbf, kbd = packed_weight(weight, bias, x.dtype)
         cout, cin = weight.shape[0], weight.shape[1]
         N, H, W, Ho, Wo = _geom(x, ks, stride)
         dx = dw = db = None
@@ -257,9 +262,9 @@ class ConvFn(torch.autograd.Function):
                 raise _lib.MdmHipError("input gradient requested for a channel-padded convolution")
             dx = torch.empty_like(x)
             if ks == 3 and stride == 2:
-                _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, 3, 1, 1, 0)
+                _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, 3, 1, 1, 0, kbd)
             else:
-                _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, ks, 1, 0, 0)
+                _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, ks, 1, 0, 0, kbd)
         if ctx.needs_input_grad[1]:
             dwp = _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride)
             if cout_pad != cout or cin_pad != cin:
@@ -288,8 +293,8 @@ class FFNFn(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2, residual, keep):
         _require_gpu(x)
         x, residual = _c(x), _c(residual)
-        wf1, _, bp1, c_in, c_hid = packed_weight(w1, b1, x.dtype)
-        wf2, _, bp2, _, c_out = packed_weight(w2, b2, x.dtype)
+        wf1, _, bp1, c_in, c_hid, _, _ = packed_weight(w1, b1, x.dtype)
+        wf2, _, bp2, _, c_out, _, _ = packed_weight(w2, b2, x.dtype)
         N, H, W, _, _ = _geom(x, 1, 1)
         pre = torch.empty(_out_shape(x, H, W, c_hid), dtype=x.dtype, device=x.device) if keep else None
         a = torch.empty(_out_shape(x, H, W, c_hid), dtype=x.dtype, device=x.device)
@@ -304,8 +309,8 @@ class FFNFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w1, b1, w2, b2, pre, a = ctx.saved_tensors
         dy = _c(dy)
-        _, wd1, _, c_in, c_hid = packed_weight(w1, b1, x.dtype)
-        _, wd2, _, _, c_out = packed_weight(w2, b2, x.dtype)
+        _, wd1, _, c_in, c_hid, _, _ = packed_weight(w1, b1, x.dtype)
+        _, wd2, _, _, c_out, _, _ = packed_weight(w2, b2, x.dtype)
         N, H, W, _, _ = _geom(x, 1, 1)
         M = N * H * W
         dpre = torch.empty_like(pre)

@@ -40,7 +40,7 @@ def test_invalid_arguments_rejected_before_launch():
     from mdm_hip import _lib
 
     L = _lib.lib()
-    rc = L.mdm_conv_fwd(None, None, None, None, None, None, None, 1, 8, 8, 8, 8, 8, 8, 3, 1, 0, 0, 1, None)
+    rc = L.mdm_conv_fwd(None, None, None, None, None, None, None, 1, 8, 8, 8, 8, 8, 8, 3, 1, 0, 0, 0, 1, None)
     assert rc < 0
     rc = L.mdm_attn_fwd(None, None, None, None, None, None, None, 1, 64, 0, 8, 32, 1, None)
     assert rc < 0

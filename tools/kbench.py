@@ -53,17 +53,17 @@ def main():
         x = torch.randn(B, H, H, cin, device=dev).to(DT)
         w = (torch.randn(cout, cin, ks, ks, device=dev) / (cin * ks * ks) ** 0.5)
         b = torch.randn(cout, device=dev)
-        wf, wd, bp, cin_p, cout_p = ops.packed_weight(w, b, DT)
+        wf, wd, bp, cin_p, cout_p, kbf, kbd = ops.packed_weight(w, b, DT)
         Ho = (H - 1) // stride + 1
         y = torch.empty(B, Ho, Ho, cout, device=dev, dtype=DT)
         flops = 2.0 * B * Ho * Ho * cout * cin * ks * ks
         line = "%-22s" % name
         if what in ("fwd", "all"):
-            t = timeit(lambda: ops._conv_launch(x, wf, bp, None, None, y, None, B, H, H, cin, Ho, Ho, cout, ks, stride, 0, 0))
+            t = timeit(lambda: ops._conv_launch(x, wf, bp, None, None, y, None, B, H, H, cin, Ho, Ho, cout, ks, stride, 0, 0, kbf))
             line += "  fwd %7.3f ms %7.1f TF" % (t * 1e3, flops / t / 1e12)
         if what in ("dgrad", "all") and stride == 1:
             dx = torch.empty_like(x)
-            t = timeit(lambda: ops._conv_launch(y, wd, None, None, None, dx, None, B, Ho, Ho, cout, H, H, cin, ks, 1, 0, 0))
+            t = timeit(lambda: ops._conv_launch(y, wd, None, None, None, dx, None, B, Ho, Ho, cout, H, H, cin, ks, 1, 0, 0, kbd))
             line += "  dgrad %7.3f ms %7.1f TF" % (t * 1e3, flops / t / 1e12)
         if what in ("wgrad", "all"):
             t = timeit(lambda: ops._wgrad_launch(x, y, B, H, H, cin, Ho, Ho, cout, ks, stride))
