@@ -51,6 +51,9 @@ const char* mdm_last_error(void);
  *   (transposed = 1 for the gradient of a stride-2 convolution: Ho = 2H, Wo = 2W).
  * mdm_conv_wgrad: dw (Cout, Cin, k, k) fp32 = sum_m dy[m, :] (x) im2col(x)[m, :]; ws from mdm_conv_wgrad_plan.
  * mdm_colsum: out[c] = sum_m x[m, c]  (bias gradients); ws from mdm_colsum_plan.
+ *   `accumulate` != 0 (here and in mdm_gn_bwd / mdm_ln_bwd) adds the parameter gradient into the destination
+ *   instead of overwriting it: the caller points it at the parameter's slot of a flat gradient arena, which
+ *   removes the per-parameter "grad += new" kernels of the autograd engine.
  */
 int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int ksize, int Cin_pad,
                     int Cout_pad, int kblock_fwd, int kblock_dgrad, int dtype, void* stream);
@@ -59,9 +62,9 @@ int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const v
                  int transposed, int act, int kblock, int dtype, void* stream);
 int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes);
 int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, float* ws, int N, int H, int W, int Cin, int Ho,
-                   int Wo, int Cout, int ksize, int stride, int dtype, void* stream);
+                   int Wo, int Cout, int ksize, int stride, int accumulate, int dtype, void* stream);
 int mdm_colsum_plan(int M, int C, int* nblocks, size_t* ws_bytes);
-int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int dtype, void* stream);
+int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulate, int dtype, void* stream);
 
 /* ---- GroupNorm (+FiLM) (+SiLU), LayerNorm -----------------------------------------------
  * replaces nn.GroupNorm + F.silu + the FiLM modulation `norm2(h) * (1 + ta) + tb`
@@ -76,12 +79,12 @@ int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, const void*
                float* coef, float* ws, int N, int HW, int C, int G, float eps, int act, int dtype, void* stream);
 int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* film,
                const float* stats, const float* coef, void* dx, float* dgamma, float* dbeta, void* dfilm, float* ws,
-               int N, int HW, int C, int G, int act, int dtype, void* stream);
+               int N, int HW, int C, int G, int act, int accumulate, int dtype, void* stream);
 int mdm_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int R, int D, float eps,
                int dtype, void* stream);
 /* ws: fp32 [ceil(R/64)][D][2] */
 int mdm_ln_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, float* dgamma,
-               float* dbeta, float* ws, int R, int D, int dtype, void* stream);
+               float* dbeta, float* ws, int R, int D, int accumulate, int dtype, void* stream);
 
 /* ---- fused self + text cross attention ---------------------------------------------------
  * replaces SelfAttention.attention x2 + the sum (unet.py:276-307): einsum QK^T, fp32 softmax, einsum PV.
@@ -117,6 +120,19 @@ int mdm_sincos_emb(const float* times, const float* freqs, void* out, int B, int
 int mdm_masked_mean(const void* x, const float* mask, void* y, int B, int S, int D, int dtype, void* stream);
 int mdm_masked_mean_bwd(const void* dy, const float* mask, void* dx, int B, int S, int D, int accumulate, int dtype,
                         void* stream);
+
+/* ---- optimizer tail over flat fp32 arenas ---------------------------------------------------
+ * replaces clip_grad_norm_ + AdamW.step + ModelEma.update + zero_grad (trainer.py:52-58,79-92;
+ * clis/train_parallel.py:122-127; models/model_ema.py:25-34) -- thousands of per-tensor kernels in the
+ * reference -- by two streaming passes.  All arenas hold the parameters in the same order.
+ *   mdm_sumsq:          out[0] = sum g^2 (device scalar, no host sync); ws = fp32[1024]
+ *   mdm_adamw_ema_step: gs = gnorm_sq ? min(1, clip / (sqrt(*gnorm_sq) + 1e-6)) : 1; AdamW on (p, gs*g, m, v) with
+ *                       bias correction for 1-based `step`; ema = ema*d + p*(1-d) if ema != NULL; g = 0 if zero_grad.
+ */
+int mdm_sumsq(const float* g, float* out, float* ws, size_t n, void* stream);
+int mdm_adamw_ema_step(float* p, float* g, float* m, float* v, float* ema, const float* gnorm_sq, size_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int step, float clip, float ema_decay,
+                       int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

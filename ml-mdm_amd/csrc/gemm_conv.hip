@@ -839,7 +839,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArg
 
 // dW_oihw[o][i][t] = sum_s slab[s][o][t*Cin + i]      (taps = 1 or 9)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
-                                    int Cout, int Cin, int taps) {
+                                    int Cout, int Cin, int taps, int accumulate) {
   const size_t total = (size_t)Cout * Cin * taps;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
@@ -849,7 +849,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     const int tp = k / Cin, i = k - tp * Cin;
     float s = 0.f;
     for (int sp = 0; sp < splits; ++sp) s += slab[(size_t)sp * total + idx];
-    dw[((size_t)o * Cin + i) * taps + tp] = s;
+    float* dst = dw + ((size_t)o * Cin + i) * taps + tp;
+    *dst = accumulate ? *dst + s : s;
   }
 }
 
@@ -920,12 +921,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     if (ch < C) part[(size_t)blockIdx.y * C + ch] = a;
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nslabs, int C) {
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nslabs, int C,
+                                    int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
   for (int b = 0; b < nslabs; ++b) s += part[(size_t)b * C + c];
-  out[c] = s;
+  out[c] = accumulate ? out[c] + s : s;
 }
 
 }  // namespace mdm
@@ -1050,7 +1052,8 @@ static void wgrad_set_smem(K kern, int bytes) {
 }
 
 extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, float* ws, int N, int H, int W,
-                              int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int dtype, void* stream) {
+                              int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int accumulate, int dtype,
+                              void* stream) {
   MDM_CHECK_ARG(x && dy && dw_oihw && ws);
   MDM_CHECK_ARG(ksize == 1 || ksize == 3);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
@@ -1093,7 +1096,7 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, flo
   }
   const size_t total = (size_t)Cout * a.K;
   const int rb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, ws, dw_oihw, a.splits, Cout, Cin, ksize * ksize);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, ws, dw_oihw, a.splits, Cout, Cin, ksize * ksize, accumulate);
   MDM_LAUNCH_STATUS();
 }
 
@@ -1135,7 +1138,8 @@ extern "C" int mdm_colsum_plan(int M, int C, int* nblocks, size_t* ws_bytes) {
   return 0;
 }
 
-extern "C" int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int dtype, void* stream) {
+extern "C" int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulate, int dtype,
+                          void* stream) {
   MDM_CHECK_ARG(x && out && ws);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
   const int epv = dtype == DT_F32 ? 4 : 8;
@@ -1148,6 +1152,6 @@ extern "C" int mdm_colsum(const void* x, float* out, float* ws, int M, int C, in
     hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(groups, slabs), dim3(256), 0, st, (const float*)x, ws, M, C, rps);
   else
     hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(groups, slabs), dim3(256), 0, st, (const bf16*)x, ws, M, C, rps);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, out, slabs, C);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, out, slabs, C, accumulate);
   MDM_LAUNCH_STATUS();
 }

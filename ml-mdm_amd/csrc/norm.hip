@@ -246,12 +246,13 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
 
 // dgamma[c] = sum_n pgrad[n][c][0]; dbeta[c] = sum_n pgrad[n][c][1]
 __global__ void gn_bwd_param_kernel(const float* __restrict__ pgrad, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, int N, int C) {
+                                    float* __restrict__ dbeta, int N, int C, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float a = 0.f, b = 0.f;
   for (int n = 0; n < N; ++n) { a += pgrad[((size_t)n * C + c) * 2]; b += pgrad[((size_t)n * C + c) * 2 + 1]; }
-  dgamma[c] = a; dbeta[c] = b;
+  dgamma[c] = accumulate ? dgamma[c] + a : a;
+  dbeta[c] = accumulate ? dbeta[c] + b : b;
 }
 
 // ---- backward stage 3: dx = a*dz + q*x + r ------------------------------------------
@@ -358,12 +359,13 @@ __global__ __launch_bounds__(256) void ln_bwd_param_partial_kernel(const T* __re
   part[((size_t)blockIdx.y * D + i) * 2 + 1] = b;
 }
 __global__ void ln_bwd_param_final_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                          float* __restrict__ dbeta, int nslabs, int D) {
+                                          float* __restrict__ dbeta, int nslabs, int D, int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= D) return;
   float a = 0.f, b = 0.f;
   for (int s = 0; s < nslabs; ++s) { a += part[((size_t)s * D + i) * 2]; b += part[((size_t)s * D + i) * 2 + 1]; }
-  dgamma[i] = a; dbeta[i] = b;
+  dgamma[i] = accumulate ? dgamma[i] + a : a;
+  dbeta[i] = accumulate ? dbeta[i] + b : b;
 }
 
 }  // namespace mdm
@@ -416,7 +418,7 @@ extern "C" int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, 
 
 extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* film,
                           const float* stats, const float* coef, void* dx, float* dgamma, float* dbeta, void* dfilm,
-                          float* ws, int N, int HW, int C, int G, int act, int dtype, void* stream) {
+                          float* ws, int N, int HW, int C, int G, int act, int accumulate, int dtype, void* stream) {
   MDM_CHECK_ARG(dy && x && gamma && beta && stats && coef && dx && dgamma && dbeta && ws);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
   MDM_CHECK_ARG((film == nullptr) == (dfilm == nullptr));
@@ -435,7 +437,8 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
                      (const TT*)x, coef, part, HW, C, slabs, pps);                                                   \
   hipLaunchKernelGGL(gn_bwd_finalize_kernel<TT>, dim3(N), dim3(256), 0, st, part, stats, gamma, beta,                \
                      (const TT*)film, qr, (TT*)dfilm, pgrad, HW, C, G, slabs);                                       \
-  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, pgrad, dgamma, dbeta, N, C);      \
+  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, pgrad, dgamma, dbeta, N, C,      \
+                     accumulate);                                                                                    \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, ACT>), dim3(ab), dim3(256), 0, st, (const TT*)dy, (const TT*)x, coef, \
                      qr, (TT*)dx, HW, C, G, total_chunks);
   if (dtype == DT_F32) { if (act) { MDM_GN_BWD(float, 1) } else { MDM_GN_BWD(float, 0) } }
@@ -456,7 +459,8 @@ extern "C" int mdm_ln_fwd(const void* x, const float* gamma, const float* beta, 
 
 // ws: fp32 [ceil(R/64)][D][2]
 extern "C" int mdm_ln_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
-                          float* dgamma, float* dbeta, float* ws, int R, int D, int dtype, void* stream) {
+                          float* dgamma, float* dbeta, float* ws, int R, int D, int accumulate, int dtype,
+                          void* stream) {
   MDM_CHECK_ARG(dy && x && gamma && stats && dx && dgamma && dbeta && ws);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int rpb = 64, nsl = (R + rpb - 1) / rpb;
@@ -467,6 +471,6 @@ extern "C" int mdm_ln_bwd(const void* dy, const void* x, const float* gamma, con
     hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(R), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, D);
     hipLaunchKernelGGL(ln_bwd_param_partial_kernel<bf16>, dim3((D + 255) / 256, nsl), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, stats, ws, R, D, rpb);
   } else MDM_CHECK_ARG(false);
-  hipLaunchKernelGGL(ln_bwd_param_final_kernel, dim3((D + 255) / 256), dim3(256), 0, st, ws, dgamma, dbeta, nsl, D);
+  hipLaunchKernelGGL(ln_bwd_param_final_kernel, dim3((D + 255) / 256), dim3(256), 0, st, ws, dgamma, dbeta, nsl, D, accumulate);
   MDM_LAUNCH_STATUS();
 }

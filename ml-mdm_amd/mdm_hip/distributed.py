@@ -82,6 +82,7 @@ class GradReducer:
                 b_start = off
         if off > b_start:
             self.buckets.append((b_start, off))
+        self._slots = {p.data_ptr(): (p, p.grad) for p in self.params}   # gradient-sink lookup (see ops.set_grad_sink)
         self._need = [0] * len(self.buckets)
         for p in order:
             self._need[self._bucket_of[p]] += 1
@@ -92,7 +93,20 @@ class GradReducer:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
 
-    # -- called by autograd, once per parameter per backward
+    # -- gradient-sink interface (mdm_hip.ops.set_grad_sink): backward kernels add straight into the arena
+    def slot(self, p):
+        ent = self._slots.get(p.data_ptr())
+        return ent[1] if ent is not None and ent[0].shape == p.shape else None
+
+    def ready(self, p):
+        if self.world > 1:
+            self._hook(self._slots[p.data_ptr()][0])
+
+    def rebind(self):
+        """refresh the sink lookup after the parameters' storage moved (e.g. into a flat parameter arena)"""
+        self._slots = {p.data_ptr(): (p, p.grad) for p in self.params}
+
+    # -- called by autograd (or by ready()), once per parameter per backward
     def _hook(self, p):
         if not self._enabled:
             return

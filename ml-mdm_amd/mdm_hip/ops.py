@@ -57,6 +57,35 @@ def _c(t):
 # packed-weight cache
 # --------------------------------------------------------------------------------------
 _wcache = {}  # id(param) -> (weakref to the param, {dtype: (version key, packed tensors)})
+_pack_epoch = 0
+
+
+def invalidate_packed_weights():
+    """Force a re-pack of every cached kernel-layout weight on next use.  Needed after parameter updates that
+    do not bump ``Tensor._version`` (torch's fused optimizers, our own fused optimizer kernel)."""
+    global _pack_epoch
+    _pack_epoch += 1
+
+
+# --------------------------------------------------------------------------------------
+# gradient sink: parameter gradients written straight into a flat arena
+# --------------------------------------------------------------------------------------
+_grad_sink = None
+
+
+def set_grad_sink(sink):
+    """``sink.slot(param)`` -> fp32 view of the parameter's slot in a flat gradient arena (or None) and
+    ``sink.ready(param)`` is called once the gradient has been added there.  With a sink installed the backward
+    kernels accumulate into the arena (C ABI ``accumulate`` flag) and return no gradient to autograd, which removes
+    one ``grad += new`` kernel per parameter per step.  ``None`` restores plain autograd semantics."""
+    global _grad_sink
+    _grad_sink = sink
+
+
+def _slot(param):
+    if _grad_sink is None or param is None:
+        return None
+    return _grad_sink.slot(param)
 
 
 def _cache_slot(weight):
@@ -77,7 +106,7 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
     ``(Cout, Cin, k, k)`` or ``(Cout, Cin)``; refreshed when the parameter version changes."""
     key = dtype
     ent = _cache_slot(weight)
-    ver = (weight._version, None if bias is None else bias._version, weight.data_ptr())
+    ver = (weight._version, None if bias is None else bias._version, weight.data_ptr(), _pack_epoch)
     if key in ent and ent[key][0] == ver:
         return ent[key][1]
     _require_gpu(weight)
@@ -182,17 +211,19 @@ def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, 
     return _prof_wrap(name, flops, go)
 
 
-def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride):
+def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride, out=None):
+    """dW (Cout, Cin, ks, ks) fp32; with ``out`` (a gradient-arena slot) the result is ADDED into it"""
     L = _lib.lib()
     splits = ctypes.c_int(0)
     wsb = ctypes.c_size_t(0)
     M, K = N * Ho * Wo, ks * ks * Cin
     _lib.check(L.mdm_conv_wgrad_plan(M, Cout, K, _dt(x), ctypes.byref(splits), ctypes.byref(wsb)), "mdm_conv_wgrad_plan")
     ws = _f32_ws(wsb.value, x.device)
-    dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device)
+    dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device) if out is None else out
 
     def go():
-        _lib.check(L.mdm_conv_wgrad(_p(x), _p(dy), _p(dw), _p(ws), N, H, W, Cin, Ho, Wo, Cout, ks, stride, _dt(x), _stream()),
+        _lib.check(L.mdm_conv_wgrad(_p(x), _p(dy), _p(dw), _p(ws), N, H, W, Cin, Ho, Wo, Cout, ks, stride,
+                                    0 if out is None else 1, _dt(x), _stream()),
                    "mdm_conv_wgrad")
 
     if _prof is None:
@@ -203,14 +234,16 @@ def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride):
     return dw
 
 
-def _colsum_launch(x2d, M, C):
+def _colsum_launch(x2d, M, C, out=None):
     L = _lib.lib()
     nb = ctypes.c_int(0)
     wsb = ctypes.c_size_t(0)
     _lib.check(L.mdm_colsum_plan(M, C, ctypes.byref(nb), ctypes.byref(wsb)), "mdm_colsum_plan")
     ws = _f32_ws(wsb.value, x2d.device)
-    out = torch.empty(C, dtype=torch.float32, device=x2d.device)
-    _lib.check(L.mdm_colsum(_p(x2d), _p(out), _p(ws), M, C, _dt(x2d), _stream()), "mdm_colsum")
+    acc = 0 if out is None else 1
+    if out is None:
+        out = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    _lib.check(L.mdm_colsum(_p(x2d), _p(out), _p(ws), M, C, acc, _dt(x2d), _stream()), "mdm_colsum")
     return out
 
 
@@ -265,13 +298,24 @@ class ConvFn(torch.autograd.Function):
                 _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, 3, 1, 1, 0, kbd)
             else:
                 _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, ks, 1, 0, 0, kbd)
+        padded = cout_pad != cout or cin_pad != cin
         if ctx.needs_input_grad[1]:
-            dwp = _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride)
-            if cout_pad != cout or cin_pad != cin:
-                dwp = dwp[:cout, :cin].contiguous()
-            dw = dwp.view(weight.shape)
+            slot = None if padded else _slot(weight)
+            if slot is not None:
+                _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, out=slot)
+                _grad_sink.ready(weight)
+            else:
+                dwp = _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride)
+                if padded:
+                    dwp = dwp[:cout, :cin].contiguous()
+                dw = dwp.view(weight.shape)
         if bias is not None and ctx.needs_input_grad[2]:
-            db = _colsum_launch(dy, N * Ho * Wo, cout_pad)[:cout]
+            slot = None if cout_pad != cout else _slot(bias)
+            if slot is not None:
+                _colsum_launch(dy, N * Ho * Wo, cout_pad, out=slot)
+                _grad_sink.ready(bias)
+            else:
+                db = _colsum_launch(dy, N * Ho * Wo, cout_pad)[:cout]
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None
 
@@ -315,14 +359,22 @@ class FFNFn(torch.autograd.Function):
         M = N * H * W
         dpre = torch.empty_like(pre)
         _conv_launch(dy, wd2, None, None, pre, dpre, None, N, H, W, c_out, H, W, c_hid, 1, 1, 0, 2)
-        dw2 = _wgrad_launch(a, dy, N, H, W, c_hid, H, W, c_out, 1, 1).view(w2.shape)
-        db2 = _colsum_launch(dy, M, c_out)
+        def pgrad(param, fn):
+            slot = _slot(param)
+            if slot is not None:
+                fn(slot)
+                _grad_sink.ready(param)
+                return None
+            return fn(None).view(param.shape)
+
+        dw2 = pgrad(w2, lambda o: _wgrad_launch(a, dy, N, H, W, c_hid, H, W, c_out, 1, 1, out=o))
+        db2 = pgrad(b2, lambda o: _colsum_launch(dy, M, c_out, out=o))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _conv_launch(dpre, wd1, None, None, None, dx, None, N, H, W, c_hid, H, W, c_in, 1, 1, 0, 0)
-        dw1 = _wgrad_launch(x, dpre, N, H, W, c_in, H, W, c_hid, 1, 1).view(w1.shape)
-        db1 = _colsum_launch(dpre, M, c_hid)
+        dw1 = pgrad(w1, lambda o: _wgrad_launch(x, dpre, N, H, W, c_in, H, W, c_hid, 1, 1, out=o))
+        db1 = pgrad(b1, lambda o: _colsum_launch(dpre, M, c_hid, out=o))
         dres = dy if (ctx.has_res and ctx.needs_input_grad[5]) else None
         return dx, dw1, db1, dw2, db2, dres, None
 
@@ -372,15 +424,21 @@ class GroupNormFn(torch.autograd.Function):
         HW = x.numel() // (N * C)
         g32, b32 = _c(gamma.detach().float()), _c(beta.detach().float())
         dx = torch.empty_like(x)
-        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        sg, sb = _slot(gamma), _slot(beta)
+        sunk = sg is not None and sb is not None
+        dgamma = sg if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = sb if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
         dfilm = torch.empty_like(film) if film is not None else None
         ws = _gn_ws(N, HW, C, ctx.groups, x.device)
         _lib.check(
             _lib.lib().mdm_gn_bwd(_p(dy), _p(x), _p(g32), _p(b32), _p(film), _p(stats), _p(coef), _p(dx), _p(dgamma),
-                                  _p(dbeta), _p(dfilm), _p(ws), N, HW, C, ctx.groups, ctx.act, _dt(x), _stream()),
+                                  _p(dbeta), _p(dfilm), _p(ws), N, HW, C, ctx.groups, ctx.act, 1 if sunk else 0, _dt(x), _stream()),
             "mdm_gn_bwd",
         )
+        if sunk:
+            _grad_sink.ready(gamma)
+            _grad_sink.ready(beta)
+            return dx, None, None, dfilm, None, None, None
         return dx, dgamma, dbeta, dfilm, None, None, None
 
 
@@ -399,21 +457,28 @@ class LayerNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty((R, 2), dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().mdm_ln_fwd(_p(x), _p(g32), _p(b32), _p(y), _p(stats), R, D, float(eps), _dt(x), _stream()), "mdm_ln_fwd")
-        ctx.save_for_backward(x, gamma, stats)
+        ctx.save_for_backward(x, gamma, beta, stats)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, stats = ctx.saved_tensors
+        x, gamma, beta, stats = ctx.saved_tensors
         dy = _c(dy)
         D = x.shape[-1]
         R = x.numel() // D
         g32 = _c(gamma.detach().float())
         dx = torch.empty_like(x)
-        dgamma = torch.empty(D, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(D, dtype=torch.float32, device=x.device)
+        sg, sb = _slot(gamma), _slot(beta)
+        sunk = sg is not None and sb is not None
+        dgamma = sg if sunk else torch.empty(D, dtype=torch.float32, device=x.device)
+        dbeta = sb if sunk else torch.empty(D, dtype=torch.float32, device=x.device)
         ws = torch.empty(((R + 63) // 64) * D * 2, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().mdm_ln_bwd(_p(dy), _p(x), _p(g32), _p(stats), _p(dx), _p(dgamma), _p(dbeta), _p(ws), R, D, _dt(x), _stream()), "mdm_ln_bwd")
+        _lib.check(_lib.lib().mdm_ln_bwd(_p(dy), _p(x), _p(g32), _p(stats), _p(dx), _p(dgamma), _p(dbeta), _p(ws), R, D,
+                                         1 if sunk else 0, _dt(x), _stream()), "mdm_ln_bwd")
+        if sunk:
+            _grad_sink.ready(gamma)
+            _grad_sink.ready(beta)
+            return dx, None, None, None
         return dx, dgamma, dbeta, None
 
 
@@ -685,3 +750,27 @@ class MaskedMeanFn(torch.autograd.Function):
 
 def masked_mean(x, mask):
     return MaskedMeanFn.apply(x, mask)
+
+
+# --------------------------------------------------------------------------------------
+# optimizer tail
+# --------------------------------------------------------------------------------------
+def sumsq(flat_f32, out=None):
+    """device scalar sum(g^2) of a flat fp32 arena (no host sync)"""
+    _require_gpu(flat_f32)
+    out = torch.empty(1, dtype=torch.float32, device=flat_f32.device) if out is None else out
+    ws = torch.empty(1024, dtype=torch.float32, device=flat_f32.device)
+    _lib.check(_lib.lib().mdm_sumsq(_p(flat_f32), _p(out), _p(ws), flat_f32.numel(), _stream()), "mdm_sumsq")
+    return out
+
+
+def adamw_ema_step(p, g, m, v, ema, gnorm_sq, lr, beta1, beta2, eps, weight_decay, step, clip, ema_decay, zero_grad=True):
+    """one fused clip + AdamW + EMA (+ zero-grad) pass over flat fp32 arenas; invalidates the packed-weight cache"""
+    _require_gpu(p)
+    _lib.check(
+        _lib.lib().mdm_adamw_ema_step(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(gnorm_sq), p.numel(), float(lr), float(beta1),
+                                      float(beta2), float(eps), float(weight_decay), int(step), float(clip), float(ema_decay),
+                                      1 if zero_grad else 0, _stream()),
+        "mdm_adamw_ema_step",
+    )
+    invalidate_packed_weights()

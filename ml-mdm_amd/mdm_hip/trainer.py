@@ -5,28 +5,66 @@ Mirrors ``ml_mdm.trainer.train_batch`` (reference trainer.py:13-96), the optimiz
 ``clis/train_parallel.py:122-134`` (AdamW, weight_decay 0, eps 1e-8) and ``ModelEma.update``
 (models/model_ema.py:25-34; the EMA here tracks parameters -- the model has no persistent
 buffers).  bf16 needs no loss scaling, so the reference's GradScaler is not reproduced.
-The optimizer tail currently runs as torch multi-tensor ops over the flat gradient arena
-(fusing clip + AdamW + EMA + weight re-pack into one HIP pass
-is the next step).
+On the GPU the optimizer tail is fused: gradients land directly in a flat arena
+and ``mdm_sumsq`` + ``mdm_adamw_ema_step`` do clip + AdamW + EMA + zero-grad in two streaming passes.
 """
 import torch
 
+from . import ops
 from .distributed import GradReducer
 
 
 class TrainStep:
+    """fused=True (GPU): parameters, gradients, Adam moments and the EMA live in flat fp32 arenas; backward kernels
+    add parameter gradients straight into the gradient arena (ops.set_grad_sink) and the whole optimizer tail is
+    ``mdm_sumsq`` + ``mdm_adamw_ema_step`` (clip, AdamW, EMA, zero-grad in one pass).  fused=False keeps torch's
+    optimizer (CPU tests, or as a cross-check)."""
+
     def __init__(self, pipeline, lr=5e-5, clip_norm=2.0, ema_decay=0.9999, bf16=True, use_ema=True,
-                 bucket_mb=256.0, wire_dtype=None):
+                 bucket_mb=256.0, wire_dtype=None, fused=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.pipeline = pipeline
         self.net = pipeline.get_model().vision_model
         self.params = [p for p in self.net.parameters() if p.requires_grad]
         self.reducer = GradReducer(self.params, bucket_mb=bucket_mb, wire_dtype=wire_dtype)
         self.reducer.broadcast_parameters(0)
-        self.opt = torch.optim.AdamW(self.params, lr=lr, weight_decay=0, eps=1e-8, fused=self.params[0].is_cuda)
-        self.clip_norm, self.bf16 = clip_norm, bf16
-        self.ema_decay = ema_decay
-        self.ema = [p.detach().clone() for p in self.params] if use_ema else None
+        self.fused = self.params[0].is_cuda if fused is None else fused
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.clip_norm, self.bf16, self.ema_decay = clip_norm, bf16, ema_decay
         self.steps = 0
+        if self.fused:
+            # flat parameter arena in the SAME order as the gradient arena (reverse registration order)
+            flat = torch.empty_like(self.reducer.flat)
+            off = 0
+            with torch.no_grad():
+                for p in reversed(self.params):
+                    n = p.numel()
+                    flat[off:off + n].copy_(p.reshape(-1))
+                    p.data = flat[off:off + n].view_as(p)
+                    off += n
+            self.flat_p = flat
+            self.m = torch.zeros_like(flat)
+            self.v = torch.zeros_like(flat)
+            self.flat_ema = flat.clone() if use_ema else None
+            self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            self.reducer.rebind()
+            ops.set_grad_sink(self.reducer)
+            ops.invalidate_packed_weights()
+            self.opt = None
+            self.ema = None
+        else:
+            self.opt = torch.optim.AdamW(self.params, lr=lr, betas=betas, weight_decay=weight_decay, eps=eps)
+            self.ema = [p.detach().clone() for p in self.params] if use_ema else None
+
+    def ema_state(self):
+        """name -> EMA tensor (views of the flat EMA arena in fused mode)"""
+        names = {id(p): n for n, p in self.net.named_parameters()}
+        if self.fused:
+            out, off = {}, 0
+            for p in reversed(self.params):
+                out[names[id(p)]] = self.flat_ema[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            return out
+        return {names[id(p)]: e for p, e in zip(self.params, self.ema)}
 
     def __call__(self, sample, **loss_kw):
         self.pipeline.train()
@@ -40,13 +78,20 @@ class TrainStep:
             return loss_val
         loss.backward()
         self.reducer.finish()
+        self.steps += 1
+        if self.fused:
+            ops.sumsq(self.reducer.flat, out=self.gnorm_sq)
+            ops.adamw_ema_step(self.flat_p, self.reducer.flat, self.m, self.v, self.flat_ema, self.gnorm_sq, self.lr,
+                               self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps, self.clip_norm,
+                               self.ema_decay, zero_grad=True)
+            return loss_val
         gnorm = torch.linalg.vector_norm(self.reducer.flat)
         scale = torch.clamp(self.clip_norm / (gnorm + 1e-6), max=1.0)
         self.reducer.flat.mul_(scale)  # == clip_grad_norm_ over all parameters (one pass over the arena)
         self.opt.step()
+        ops.invalidate_packed_weights()
         if self.ema is not None:
             with torch.no_grad():
                 torch._foreach_lerp_(self.ema, [p.detach() for p in self.params], 1.0 - self.ema_decay)
         self.reducer.zero_grad()
-        self.steps += 1
         return loss_val

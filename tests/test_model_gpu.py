@@ -126,3 +126,67 @@ def test_four_step_sampling_and_loss_match_reference_pipeline(name):
     pipe.train()
     loss = pipe.get_loss(smp, time=time.cuda(), noise_fn=lambda like: next(it).to(like.device))[0]
     assert O.rel_l2(loss.float().cpu(), gold["loss"]) < 1e-3
+
+
+def test_fused_train_step_matches_torch_optimizer():
+    """TrainStep(fused=True): gradient sink + mdm_sumsq + mdm_adamw_ema_step  ==  autograd accumulation +
+    clip_grad_norm_-style scaling + torch.optim.AdamW + EMA lerp, over 3 steps on the same batch / timesteps / noise."""
+    from mdm_hip import ops
+    from mdm_hip.trainer import TrainStep
+
+    results = []
+    for fused in (False, True):
+        ops.set_grad_sink(None)
+        model, _, _ = PC.build_module("mini_unet")
+        pipe = _pipeline("mini_unet", model).to(torch.device("cuda:0"))
+        step = TrainStep(pipe, bf16=False, lr=1e-3, clip_norm=0.5, ema_decay=0.9, fused=fused)
+        inp = PC.inputs("mini_unet")
+        g = torch.Generator().manual_seed(29)
+        smp = {"lm_outputs": inp["cond"].cuda(), "lm_mask": inp["mask"].cuda(),
+               "images": (torch.rand(2, 3, 16, 16, generator=g) * 2 - 1).cuda()}
+        noise = torch.randn(2, 3, 16, 16, generator=g).cuda()
+        losses = [step(smp, time=torch.tensor([100, 700]).cuda(), noise_fn=lambda like: noise) for _ in range(3)]
+        params = {k: v.detach().float().cpu().clone() for k, v in model.named_parameters()}
+        ema = {k: v.detach().float().cpu().clone() for k, v in step.ema_state().items()}
+        results.append((losses, params, ema))
+    ops.set_grad_sink(None)
+    (l0, p0, e0), (l1, p1, e1) = results
+    assert all(abs(a - b) <= 1e-4 * abs(a) + 1e-7 for a, b in zip(l0, l1)), (l0, l1)
+    assert l0[2] < l0[0]
+    # Adam normalises every gradient to +-lr, including the pure-rounding-noise gradients of parameters whose true
+    # gradient is zero (conv bias in front of a 1-channel-per-group GroupNorm): those few tensors differ by O(lr)
+    # between ANY two fp32 implementations, so the check is aggregate plus a loose per-tensor bound.
+    def agg(a, b):
+        num = sum(float((a[k].double() - b[k].double()).pow(2).sum()) for k in a)
+        den = sum(float(b[k].double().pow(2).sum()) for k in a)
+        return (num / den) ** 0.5
+
+    assert agg(p1, p0) < 1e-4 and agg(e1, e0) < 1e-4
+    for k in p0:
+        assert O.rel_l2(p1[k], p0[k]) < 5e-3, k
+
+
+def test_weights_are_repacked_after_an_optimizer_step():
+    """the packed kernel-layout weights must follow parameter updates that do not bump Tensor._version"""
+    from mdm_hip import ops
+    from mdm_hip.trainer import TrainStep
+
+    ops.set_grad_sink(None)
+    model, _, _ = PC.build_module("mini_unet")
+    pipe = _pipeline("mini_unet", model).to(torch.device("cuda:0"))
+    step = TrainStep(pipe, bf16=False, lr=5e-2, fused=True)
+    inp = PC.inputs("mini_unet")
+    args = (inp["x"].cuda(), inp["times"].cuda(), inp["cond"].cuda(), inp["mask"].cuda())
+    with torch.no_grad():
+        y0 = model(*args).clone()
+    g = torch.Generator().manual_seed(3)
+    smp = {"lm_outputs": inp["cond"].cuda(), "lm_mask": inp["mask"].cuda(), "images": (torch.rand(2, 3, 16, 16, generator=g) * 2 - 1).cuda()}
+    step(smp)
+    with torch.no_grad():
+        y1 = model(*args)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ops.set_grad_sink(None)
+    assert O.rel_l2(y1, y0) > 1e-3                      # the update is visible through the kernels
+    _, cfg, _ = PC.build_module("mini_unet")
+    y_ref = O.model_forward(sd, cfg, inp["x"], inp["times"], inp["cond"], inp["mask"])
+    assert O.rel_l2(y1.cpu(), y_ref) < 1e-4             # ... and it is exactly the updated parameters
