@@ -362,6 +362,7 @@ struct WgradArgs {
   const void* x;    // [N, H, W, Cin]
   const void* dy;   // [M, Cout]
   float* slab;      // [splits][Cout][K]
+  float* bslab;     // [splits][Cout] column sums of dY (bias gradient partials) or null
   int N, H, W, Cin, Ho, Wo, Cout, stride;
   int M, K;
   int splits, mtiles_per_split;
@@ -749,6 +750,17 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArg
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dY: the dY^T fragments are already in registers, so the blocks of k-tile 0
+  // (waves wn == 0) multiply them by an all-ones fragment -- MT extra MFMAs per k-step in 1/tiles_k of the blocks
+  const bool do_bias = p.bslab != nullptr && k0 == 0 && wn == 0;
+  f32x4 bacc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Frag<T> ones;
+  {
+    const bf16 o1 = (bf16)1.0f;
+    ones.v = bf16x8{o1, o1, o1, o1, o1, o1, o1, o1};
+  }
 
   // per-lane LDS byte addresses of the transpose reads: reduction row quad*8 + (l16>>2) (+4 for the upper half,
   // +32 rows per k-step: immediates), 16-channel column tile `c`, 4-element segment l16 & 3
@@ -783,6 +795,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArg
           for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) mma16(acc[i][j], bfr[j], af[i]);
+          if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mma16(bacc[i], ones, af[i]);
+          }
         }
         {
           Frag<T> af[8], bfr[4];
@@ -791,6 +807,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArg
           for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) mma16(acc[i][j], bfr[j], af[i]);
+          if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mma16(bacc[i], ones, af[i]);
+          }
         }
       } else {
         {
@@ -800,6 +820,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArg
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) mma16(acc[i][j], bfr[j], af[i]);
+          if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mma16(bacc[i], ones, af[i]);
+          }
         }
         {
           Frag<T> af[4], bfr[4];
@@ -808,6 +832,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArg
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) mma16(acc[i][j], bfr[j], af[i]);
+          if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mma16(bacc[i], ones, af[i]);
+          }
         }
       }
       __syncthreads();
@@ -816,6 +844,14 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArg
 #undef MDM_WG_STAGE
 #undef MDM_GLDS
 
+  if (do_bias && quad == 0) {
+    // D = ones * dY^T-fragment: every row of the 16x16 result holds the column sums; lane l16 of quad 0 owns Cout n
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int n = n0 + wm * TM + i * 16 + l16;
+      if (n < p.Cout) p.bslab[(size_t)split * p.Cout + n] = bacc[i][0];
+    }
+  }
   float* __restrict__ S = p.slab + (size_t)split * p.Cout * p.K;
   const bool vec_ok = (p.K & 3) == 0;
 #pragma unroll
@@ -838,19 +874,65 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArg
 }
 
 // dW_oihw[o][i][t] = sum_s slab[s][o][t*Cin + i]      (taps = 1 or 9)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
-                                    int Cout, int Cin, int taps, int accumulate) {
+// One block per (o, 64-channel block): the 9 x 64 slab values are read as 9 contiguous runs, transposed through
+// LDS and written as one contiguous run of 576 floats, so both sides are coalesced.  Blocks beyond the weight
+// grid reduce the bias-gradient partials bslab[s][o].
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                           const float* __restrict__ bslab, float* __restrict__ dbias,
+                                                           int splits, int Cout, int Cin, int taps, int accumulate,
+                                                           int wblocks) {
+  __shared__ float tile[64 * 9];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= wblocks) {   // bias part: 256 output channels per block
+    const int o = ((int)blockIdx.x - wblocks) * 256 + tid;
+    if (o < Cout) {
+      float s = 0.f;
+      for (int sp = 0; sp < splits; ++sp) s += bslab[(size_t)sp * Cout + o];
+      dbias[o] = accumulate ? dbias[o] + s : s;
+    }
+    return;
+  }
+  const int iblocks = (Cin + 63) / 64;
+  const int o = blockIdx.x / iblocks, i0 = (blockIdx.x - o * iblocks) * 64;
+  const int ni = min(64, Cin - i0);
   const size_t total = (size_t)Cout * Cin * taps;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    // idx enumerates the *packed* layout (coalesced slab reads)
-    const int K = Cin * taps;
-    const int o = (int)(idx / K), k = (int)(idx - (size_t)o * K);
-    const int tp = k / Cin, i = k - tp * Cin;
+  const int K = Cin * taps;
+  for (int e = tid; e < taps * 64; e += 256) {
+    const int tp = e >> 6, il = e & 63;
     float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += slab[(size_t)sp * total + idx];
-    float* dst = dw + ((size_t)o * Cin + i) * taps + tp;
-    *dst = accumulate ? *dst + s : s;
+    if (il < ni) {
+      const size_t src = (size_t)o * K + (size_t)tp * Cin + i0 + il;
+      for (int sp = 0; sp < splits; ++sp) s += slab[(size_t)sp * total + src];
+    }
+    tile[il * taps + tp] = s;
+  }
+  __syncthreads();
+  float* dst = dw + ((size_t)o * Cin + i0) * taps;
+  for (int e = tid; e < ni * taps; e += 256) dst[e] = accumulate ? dst[e] + tile[e] : tile[e];
+}
+
+// taps == 1: packed and reference layouts coincide -> flat, fully coalesced reduction (grid-stride); the last
+// `bblocks` blocks reduce the bias partials
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                const float* __restrict__ bslab,
+                                                                float* __restrict__ dbias, int splits, int Cout,
+                                                                size_t total, int accumulate, int wblocks) {
+  if ((int)blockIdx.x >= wblocks) {
+    const int o = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+    if (o < Cout) {
+      float s = 0.f;
+      for (int sp = 0; sp < splits; ++sp) s += bslab[(size_t)sp * Cout + o];
+      dbias[o] = accumulate ? dbias[o] + s : s;
+    }
+    return;
+  }
+  const size_t n4 = total / 4;   // Cin % 4 == 0 -> total % 4 == 0
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
+  f32x4* d4 = reinterpret_cast<f32x4*>(dw);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)wblocks * 256) {
+    f32x4 a = s4[i];
+    for (int sp = 1; sp < splits; ++sp) a += s4[(size_t)sp * n4 + i];
+    d4[i] = accumulate ? d4[i] + a : a;
   }
 }
 
@@ -1042,7 +1124,8 @@ extern "C" int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* split
   const int per = (mt_total + splits - 1) / splits;
   splits = (mt_total + per - 1) / per;
   *splits_out = splits;
-  *ws_bytes = (size_t)splits * Cout * K * sizeof(float);
+  // weight slabs + bias-gradient partials (or the column-sum workspace of the fp32 path)
+  *ws_bytes = ((size_t)splits * Cout * K + (size_t)(splits > 64 ? splits : 64) * Cout) * sizeof(float);
   return 0;
 }
 
@@ -1051,9 +1134,11 @@ static void wgrad_set_smem(K kern, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, float* ws, int N, int H, int W,
-                              int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int accumulate, int dtype,
-                              void* stream) {
+extern "C" int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulate, int dtype, void* stream);
+
+extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, float* dbias, float* ws, int N, int H,
+                              int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int accumulate,
+                              int dtype, void* stream) {
   MDM_CHECK_ARG(x && dy && dw_oihw && ws);
   MDM_CHECK_ARG(ksize == 1 || ksize == 3);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
@@ -1069,6 +1154,8 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, flo
   const int bkm = dtype == DT_F32 ? 32 : 64;
   const int mt_total = (a.M + bkm - 1) / bkm;
   a.mtiles_per_split = (mt_total + a.splits - 1) / a.splits;
+  float* const bias_ws = ws + (size_t)a.splits * Cout * a.K;
+  a.bslab = (dbias && dtype == DT_BF16) ? bias_ws : nullptr;   // the bf16 kernels fold the column sums in
   const int te = wgrad_tile(a.M, Cout, a.K, dtype);
   const int tiles = ((Cout + te - 1) / te) * ((a.K + te - 1) / te);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1094,9 +1181,18 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, flo
     if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_1x1, 0>), grid, dim3(256), smem, st, a);
     else hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_3x3, 0>), grid, dim3(256), smem, st, a);
   }
-  const size_t total = (size_t)Cout * a.K;
-  const int rb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, ws, dw_oihw, a.splits, Cout, Cin, ksize * ksize, accumulate);
+  const int bblocks = a.bslab ? (Cout + 255) / 256 : 0;
+  if (ksize == 1) {
+    const size_t total = (size_t)Cout * Cin;
+    const int wblocks = (int)((total / 4 + 255) / 256 > 2048 ? 2048 : (total / 4 + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, ws, dw_oihw, a.bslab, dbias,
+                       a.splits, Cout, total, accumulate, wblocks);
+  } else {
+    const int wblocks = Cout * ((Cin + 63) / 64);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, ws, dw_oihw, a.bslab, dbias,
+                       a.splits, Cout, Cin, ksize * ksize, accumulate, wblocks);
+  }
+  if (dbias && !a.bslab) return mdm_colsum(dy, dbias, bias_ws, a.M, Cout, accumulate, dtype, stream);
   MDM_LAUNCH_STATUS();
 }
 

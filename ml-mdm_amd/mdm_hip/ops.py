@@ -211,8 +211,9 @@ def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, 
     return _prof_wrap(name, flops, go)
 
 
-def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride, out=None):
-    """dW (Cout, Cin, ks, ks) fp32; with ``out`` (a gradient-arena slot) the result is ADDED into it"""
+def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride, out=None, dbias=None):
+    """dW (Cout, Cin, ks, ks) fp32; with ``out`` (a gradient-arena slot) the result is ADDED into it.  ``dbias`` (fp32
+    [Cout]) receives the bias gradient from the same launch, with the same overwrite / accumulate semantics."""
     L = _lib.lib()
     splits = ctypes.c_int(0)
     wsb = ctypes.c_size_t(0)
@@ -222,7 +223,7 @@ def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride, out=None):
     dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device) if out is None else out
 
     def go():
-        _lib.check(L.mdm_conv_wgrad(_p(x), _p(dy), _p(dw), _p(ws), N, H, W, Cin, Ho, Wo, Cout, ks, stride,
+        _lib.check(L.mdm_conv_wgrad(_p(x), _p(dy), _p(dw), _p(dbias), _p(ws), N, H, W, Cin, Ho, Wo, Cout, ks, stride,
                                     0 if out is None else 1, _dt(x), _stream()),
                    "mdm_conv_wgrad")
 
@@ -299,17 +300,27 @@ class ConvFn(torch.autograd.Function):
             else:
                 _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, ks, 1, 0, 0, kbd)
         padded = cout_pad != cout or cin_pad != cin
+        want_b = bias is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             slot = None if padded else _slot(weight)
+            bslot = _slot(bias) if (slot is not None and want_b) else None
             if slot is not None:
-                _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, out=slot)
+                # weight (and, when it also lives in the arena, bias) gradient from one launch
+                _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, out=slot, dbias=bslot)
                 _grad_sink.ready(weight)
+                if bslot is not None:
+                    _grad_sink.ready(bias)
+                    want_b = False
             else:
-                dwp = _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride)
+                dbt = torch.empty(cout_pad, dtype=torch.float32, device=x.device) if want_b else None
+                dwp = _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, dbias=dbt)
                 if padded:
                     dwp = dwp[:cout, :cin].contiguous()
                 dw = dwp.view(weight.shape)
-        if bias is not None and ctx.needs_input_grad[2]:
+                if want_b:
+                    db = dbt[:cout]
+                    want_b = False
+        if want_b:
             slot = None if cout_pad != cout else _slot(bias)
             if slot is not None:
                 _colsum_launch(dy, N * Ho * Wo, cout_pad, out=slot)
@@ -359,22 +370,23 @@ class FFNFn(torch.autograd.Function):
         M = N * H * W
         dpre = torch.empty_like(pre)
         _conv_launch(dy, wd2, None, None, pre, dpre, None, N, H, W, c_out, H, W, c_hid, 1, 1, 0, 2)
-        def pgrad(param, fn):
-            slot = _slot(param)
-            if slot is not None:
-                fn(slot)
-                _grad_sink.ready(param)
-                return None
-            return fn(None).view(param.shape)
+        def wb_grads(xin, g, w, b, cin_, cout_):
+            """(dW, db) of a 1x1 conv from ONE wgrad launch; None entries went into the gradient arena"""
+            sw, sb = _slot(w), _slot(b)
+            if sw is not None and sb is not None:
+                _wgrad_launch(xin, g, N, H, W, cin_, H, W, cout_, 1, 1, out=sw, dbias=sb)
+                _grad_sink.ready(w)
+                _grad_sink.ready(b)
+                return None, None
+            dbt = torch.empty(cout_, dtype=torch.float32, device=xin.device)
+            return _wgrad_launch(xin, g, N, H, W, cin_, H, W, cout_, 1, 1, dbias=dbt).view(w.shape), dbt
 
-        dw2 = pgrad(w2, lambda o: _wgrad_launch(a, dy, N, H, W, c_hid, H, W, c_out, 1, 1, out=o))
-        db2 = pgrad(b2, lambda o: _colsum_launch(dy, M, c_out, out=o))
+        dw2, db2 = wb_grads(a, dy, w2, b2, c_hid, c_out)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _conv_launch(dpre, wd1, None, None, None, dx, None, N, H, W, c_hid, H, W, c_in, 1, 1, 0, 0)
-        dw1 = pgrad(w1, lambda o: _wgrad_launch(x, dpre, N, H, W, c_in, H, W, c_hid, 1, 1, out=o))
-        db1 = pgrad(b1, lambda o: _colsum_launch(dpre, M, c_hid, out=o))
+        dw1, db1 = wb_grads(x, dpre, w1, b1, c_in, c_hid)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[5]) else None
         return dx, dw1, db1, dw2, db2, dres, None
 
