@@ -88,6 +88,44 @@ def _slot(param):
     return _grad_sink.slot(param)
 
 
+# Weight gradients are off the critical path of backward (nothing downstream reads them before the optimizer), so
+# with a gradient sink installed they can run on a second HIP stream and fill the CUs that the many small kernels
+# of the main chain (norm statistics, layer-norm, reductions, tiny GEMMs) leave idle.
+_side_stream = None
+_async_wgrad = False
+
+
+def enable_async_wgrad(flag: bool):
+    global _async_wgrad
+    _async_wgrad = bool(flag)
+
+
+def side_stream():
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream()
+    return _side_stream
+
+
+def join_side_stream():
+    """make the current stream wait for everything queued on the weight-gradient stream"""
+    if _side_stream is not None:
+        torch.cuda.current_stream().wait_stream(_side_stream)
+
+
+def _off_critical_path(tensors, fn):
+    """run fn() (kernel launches that only write gradient-arena slots) on the side stream when enabled"""
+    if not (_async_wgrad and _grad_sink is not None):
+        return fn()
+    side = side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+
+
 def _cache_slot(weight):
     k = id(weight)
     ent = _wcache.get(k)
@@ -306,10 +344,14 @@ class ConvFn(torch.autograd.Function):
             bslot = _slot(bias) if (slot is not None and want_b) else None
             if slot is not None:
                 # weight (and, when it also lives in the arena, bias) gradient from one launch
-                _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, out=slot, dbias=bslot)
-                _grad_sink.ready(weight)
+                def go():
+                    _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, out=slot, dbias=bslot)
+                    _grad_sink.ready(weight)
+                    if bslot is not None:
+                        _grad_sink.ready(bias)
+
+                _off_critical_path((x, dy), go)
                 if bslot is not None:
-                    _grad_sink.ready(bias)
                     want_b = False
             else:
                 dbt = torch.empty(cout_pad, dtype=torch.float32, device=x.device) if want_b else None
@@ -374,9 +416,12 @@ class FFNFn(torch.autograd.Function):
             """(dW, db) of a 1x1 conv from ONE wgrad launch; None entries went into the gradient arena"""
             sw, sb = _slot(w), _slot(b)
             if sw is not None and sb is not None:
-                _wgrad_launch(xin, g, N, H, W, cin_, H, W, cout_, 1, 1, out=sw, dbias=sb)
-                _grad_sink.ready(w)
-                _grad_sink.ready(b)
+                def go():
+                    _wgrad_launch(xin, g, N, H, W, cin_, H, W, cout_, 1, 1, out=sw, dbias=sb)
+                    _grad_sink.ready(w)
+                    _grad_sink.ready(b)
+
+                _off_critical_path((xin, g), go)
                 return None, None
             dbt = torch.empty(cout_, dtype=torch.float32, device=xin.device)
             return _wgrad_launch(xin, g, N, H, W, cin_, H, W, cout_, 1, 1, dbias=dbt).view(w.shape), dbt

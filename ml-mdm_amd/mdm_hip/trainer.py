@@ -8,6 +8,8 @@ buffers).  bf16 needs no loss scaling, so the reference's GradScaler is not repr
 On the GPU the optimizer tail is fused: gradients land directly in a flat arena
 and ``mdm_sumsq`` + ``mdm_adamw_ema_step`` do clip + AdamW + EMA + zero-grad in two streaming passes.
 """
+import os
+
 import torch
 
 from . import ops
@@ -48,6 +50,7 @@ class TrainStep:
             self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
             self.reducer.rebind()
             ops.set_grad_sink(self.reducer)
+            ops.enable_async_wgrad(os.environ.get("MDM_HIP_ASYNC_WGRAD", "1") != "0")
             ops.invalidate_packed_weights()
             self.opt = None
             self.ema = None
@@ -77,6 +80,7 @@ class TrainStep:
             self.reducer.zero_grad()
             return loss_val
         loss.backward()
+        ops.join_side_stream()
         self.reducer.finish()
         self.steps += 1
         if self.fused:
