@@ -968,6 +968,43 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
+// Tiled pack (Cout % 32 == 0, Cin % 32 == 0, no padding): one block moves a [32 o][32 i][taps] brick.  The reference
+// layout is read in contiguous runs of 32 * taps floats per output channel, staged in LDS, and written as 64-byte
+// runs of 32 consecutive channels in both kernel layouts -- the element-wise kernel above reads the dgrad side with
+// a stride of Cin * taps floats (one cache line per element).
+template <typename T, int TAPS>
+__global__ __launch_bounds__(256) void pack_weight_tiled_kernel(const float* __restrict__ w, T* __restrict__ wf,
+                                                                T* __restrict__ wd, int Cout, int Cin, int kbf,
+                                                                int kbd) {
+  __shared__ float tile[32][32 * TAPS + 1];
+  const int ib = blockIdx.x * 32, ob = blockIdx.y * 32;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 32 * 32 * TAPS; e += 256) {
+    const int ol = e / (32 * TAPS), r = e - ol * (32 * TAPS);
+    tile[ol][r] = w[((size_t)(ob + ol) * Cin + ib) * TAPS + r];   // r = il * TAPS + tap
+  }
+  __syncthreads();
+  const size_t Kf = (size_t)TAPS * Cin, Kd = (size_t)TAPS * Cout;
+  // forward pack: for each (o, tap) 32 consecutive i
+  for (int e = tid; e < 32 * TAPS * 32; e += 256) {
+    const int il = e & 31, rest = e >> 5;
+    const int tp = rest % TAPS, ol = rest / TAPS;
+    const int i = ib + il;
+    const size_t kpos = kbf ? (size_t)(i / kbf) * TAPS * kbf + (size_t)tp * kbf + (i % kbf) : (size_t)tp * Cin + i;
+    wf[(size_t)(ob + ol) * Kf + kpos] = from_f32<T>(tile[ol][il * TAPS + tp]);
+  }
+  if (wd) {
+    // dgrad pack: for each (i, flipped tap) 32 consecutive o
+    for (int e = tid; e < 32 * TAPS * 32; e += 256) {
+      const int ol = e & 31, rest = e >> 5;
+      const int tp = rest % TAPS, il = rest / TAPS;
+      const int o = ob + ol;
+      const size_t kpos = kbd ? (size_t)(o / kbd) * TAPS * kbd + (size_t)tp * kbd + (o % kbd) : (size_t)tp * Cout + o;
+      wd[(size_t)(ib + il) * Kd + kpos] = from_f32<T>(tile[ol][il * TAPS + (TAPS - 1 - tp)]);
+    }
+  }
+}
+
 // Column sums: out[c] = sum_m x[m, c]  (bias gradients).  Two deterministic stages: a
 // (column group) x (row slab) grid of partial sums, then a per-channel sum over the slabs.
 // A block is 8 chunk columns (128 bytes of a row) x 32 row lanes.
@@ -1208,6 +1245,17 @@ extern "C" int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, 
   const size_t total = (size_t)Cout * taps * Cin_pad + (w_dgrad ? (size_t)Cin * taps * Cout_pad : 0);
   const int nb = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (Cin_pad == Cin && Cout_pad == Cout && Cin % 32 == 0 && Cout % 32 == 0) {
+    dim3 grid(Cin / 32, Cout / 32);
+#define MDM_PACK_TILED(TT, TAPS)                                                                               \
+  hipLaunchKernelGGL((pack_weight_tiled_kernel<TT, TAPS>), grid, dim3(256), 0, st, w_oihw, (TT*)w_fwd, (TT*)w_dgrad, \
+                     Cout, Cin, kblock_fwd, kblock_dgrad)
+    if (dtype == DT_F32) { if (taps == 9) MDM_PACK_TILED(float, 9); else MDM_PACK_TILED(float, 1); }
+    else if (dtype == DT_BF16) { if (taps == 9) MDM_PACK_TILED(bf16, 9); else MDM_PACK_TILED(bf16, 1); }
+    else MDM_CHECK_ARG(false);
+#undef MDM_PACK_TILED
+    MDM_LAUNCH_STATUS();
+  }
   if (dtype == DT_F32)
     hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(nb), dim3(256), 0, st, w_oihw, (float*)w_fwd, (float*)w_dgrad, Cout, Cin, taps, Cin_pad, Cout_pad, kblock_fwd, kblock_dgrad);
   else if (dtype == DT_BF16)
