@@ -109,6 +109,41 @@ __device__ __forceinline__ void load_tr_tile(char* dst, const T* src, int rs, in
   }
 }
 
+// Fragment whose rows are CHANNELS (d index c16*16 + l16) and whose 8 reduction slots are tile ROWS
+// hh*32 + quad*8 + [0, 8) -- i.e. a fragment of the transposed tile.
+//   bf16: read from the NATURAL [row][d] image with the LDS transpose read (lane i of a 16-lane group supplies
+//         row i>>2, 4-channel segment i&3 and receives channel i; tools/probes/ds_read_tr_probe.hip), so no second,
+//         transposed copy of the tile is ever staged;
+//   fp32: read from the separately staged transposed image (ds_read_tr is a 16-bit instruction).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+template <typename T, int D>
+__device__ __forceinline__ void load_frag_T(Frag<T>& f, const char* nat, const char* tr, int c16, int hh, int quad, int l16);
+template <int D>
+struct FragT {
+  static __device__ __forceinline__ void bf(Frag<bf16>& f, const char* nat, int c16, int hh, int quad, int l16) {
+    const int d = c16 * 16 + (l16 & 3) * 4;
+    const int r = hh * 32 + quad * 8 + (l16 >> 2);
+    const char* base = nat + (d >> 6) * (64 * 128) + (((d >> 2) & 1) << 3);
+    const int chunk = (d & 63) >> 3;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(base + lds_chunk_off(r, chunk)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(base + lds_chunk_off(r + 4, chunk)));
+    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    f.v = *reinterpret_cast<bf16x8*>(&v);
+  }
+};
+template <typename T, int D>
+__device__ __forceinline__ void load_frag_T(Frag<T>& f, const char* nat, const char* tr, int c16, int hh, int quad, int l16) {
+  if constexpr (sizeof(T) == 2) {
+    FragT<D>::bf(f, nat, c16, hh, quad, l16);
+  } else {
+    constexpr int KSTEPS = Tr<T>::KSTEPS;
+    load_frag<T>(f, tr + (hh / KSTEPS) * (D * 128), c16 * 16 + l16, hh % KSTEPS, quad);
+  }
+}
+
 __device__ __forceinline__ int perm_row(int kt, int r) { return (kt >> 1) * 32 + (r >> 2) * 8 + (kt & 1) * 4 + (r & 3); }
 
 // ---------------------------------------------------------------------------------------
@@ -365,7 +400,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
       __syncthreads();
       load_nat_tile<T, D>(Ks, Kp, rs, k0, nk, tid);
       load_nat_tile<T, D>(Vs, Vp, rs, k0, nk, tid);
-      load_tr_tile<T, D>(KTs, Kp, rs, k0, nk, tid);
+      if constexpr (sizeof(T) != 2) load_tr_tile<T, D>(KTs, Kp, rs, k0, nk, tid);
       __syncthreads();
       f32x4 s[QT][4], dp[QT][4];
 #pragma unroll
@@ -412,7 +447,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           Frag<T> ktf;
-          load_frag<T>(ktf, KTs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
+          load_frag_T<T, D>(ktf, Ks, KTs, dt, hh, quad, l16);
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) mma16(dq[qt][dt], ktf, dsf[qt][hh]);
         }
@@ -483,8 +518,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     __syncthreads();
     load_nat_tile<T, D>(Qs, Q, p.q_rs, q0, p.L, tid);
     load_nat_tile<T, D>(Gs, DO, p.o_rs, q0, p.L, tid);
-    load_tr_tile<T, D>(QTs, Q, p.q_rs, q0, p.L, tid);
-    load_tr_tile<T, D>(GTs, DO, p.o_rs, q0, p.L, tid);
+    if constexpr (sizeof(T) != 2) {
+      load_tr_tile<T, D>(QTs, Q, p.q_rs, q0, p.L, tid);
+      load_tr_tile<T, D>(GTs, DO, p.o_rs, q0, p.L, tid);
+    }
     if (tid < 64) {
       const int qi = q0 + tid;
       lse_s[tid] = qi < p.L ? LSE[qi] : 1e30f;
@@ -527,8 +564,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         Frag<T> a, g;
-        load_frag<T>(g, GTs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
-        load_frag<T>(a, QTs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
+        load_frag_T<T, D>(g, Gs, GTs, dt, hh, quad, l16);
+        load_frag_T<T, D>(a, Qs, QTs, dt, hh, quad, l16);
         mma16(dv[dt], g, pf[hh]);
         mma16(dk[dt], a, dsf[hh]);
       }
@@ -559,7 +596,7 @@ template <typename T, int D>
 static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   using G = AttnGeom<T, D>;
   constexpr int QT = 2;
-  constexpr int smem = G::NAT_BYTES + G::TR_BYTES;
+  constexpr int smem = G::NAT_BYTES + (G::NAT_BYTES > G::TR_BYTES ? G::NAT_BYTES : G::TR_BYTES);
   auto kern = attn_fwd_kernel<T, D, QT>;
   static bool done = false;
   if (!done) { set_smem(kern, smem); done = true; }
