@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sampling", action="store_true")
+    ap.add_argument("--sample-batch", type=int, default=None)
     args = ap.parse_args()
 
     from mdm_hip import distributed as mdist
@@ -145,6 +147,24 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # secondary metric: sampling throughput (replicas only: every rank samples its own prompts, no collective)
+    samp = None
+    if not args.no_sampling:
+        n_it = 6
+        pipe.eval()
+        sb = args.sample_batch or batch
+        ssample = synthetic_batch(sb, side, device, seed=4321 + rank)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+            pipe.sample(sb, ssample, side, device, resample_steps=True, num_inference_steps=2, ddim_eta=0)  # warm-up
+            sync()
+            ts = time.perf_counter()
+            pipe.sample(sb, ssample, side, device, resample_steps=True, num_inference_steps=n_it, ddim_eta=0)
+            sync()
+            dts = time.perf_counter() - ts
+        ms_it = dts / n_it * 1e3
+        demo_steps = 50 if args.workload == "unet64" else 100   # generate_sample.py:546-551 demo defaults
+        samp = {"ms_per_denoise_step": round(ms_it, 3), "batch_per_gpu": sb, "images_per_s_at_%d_steps" % demo_steps:
+                round(world * sb / (demo_steps * ms_it / 1e3), 3), "sampler": "DDIM eta=0, CFG off", "timed_steps": n_it}
     roof = None
     if not args.no_roofline and rank == 0:
         # one extra, untimed step with HIP events around every GEMM-class launch (on the launch stream)
@@ -182,6 +202,7 @@ def main():
                 "step_mfma_roofline_frac": round(alg_tflop_step / (ms / 1e3) / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4),
             },
             "roofline": roof,
+            "sampling": samp,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, batch)
