@@ -74,7 +74,7 @@ def cpu_baseline(workload, batch_ref):
     # vs ~10 s at 8 for the same work), so the baseline uses at most 32 host threads and reports that count
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    b = 2 if workload == "unet64" else 1
+    b = 8 if workload == "unet64" else 2   # ~10 s of host work at 32 threads
     side = 64 if workload == "unet64" else 256
     torch.manual_seed(0)
     cfg = configs.unet64_config(2048) if workload == "unet64" else configs.nested256_config(2048)
@@ -168,6 +168,7 @@ def main():
     roof = None
     if not args.no_roofline and rank == 0:
         # one extra, untimed step with HIP events around every GEMM-class launch (on the launch stream)
+        ops.enable_async_wgrad(False)   # standalone kernel durations: no concurrent weight-gradient stream
         ops.profile_begin()
         step(sample)
         torch.cuda.synchronize()

@@ -49,9 +49,10 @@ const char* mdm_last_error(void);
  *   act == MDM_ACT_DGELU_AUX multiplies by gelu'(aux) (backward through the FFN GELU, unet.py:270).
  *   The same entry computes the input gradient: pass dy as x and w_dgrad as w_packed
  *   (transposed = 1 for the gradient of a stride-2 convolution: Ho = 2H, Wo = 2W).
- * mdm_conv_wgrad: dw (Cout, Cin, k, k) fp32 = sum_m dy[m, :] (x) im2col(x)[m, :]; ws from mdm_conv_wgrad_plan.
- *   dbias != NULL additionally produces the bias gradient sum_m dy[m, :] (the bf16 kernel gets it from the dY
- *   fragments it already holds, via an all-ones MFMA operand).
+ * mdm_conv_wgrad + mdm_conv_wgrad_reduce: dw (Cout, Cin, k, k) fp32 = sum_m dy[m, :] (x) im2col(x)[m, :].
+ *   The first call runs the split GEMM into fp32 slabs in ws (size from mdm_conv_wgrad_plan); the second sums the
+ *   slabs into the reference OIHW layout.  want_bias / dbias != NULL additionally produce the bias gradient
+ *   sum_m dy[m, :] (the bf16 kernel gets it from the dY fragments it already holds, via an all-ones MFMA operand).
  * mdm_colsum: out[c] = sum_m x[m, c]  (bias gradients); ws from mdm_colsum_plan.
  *   `accumulate` != 0 (here and in mdm_gn_bwd / mdm_ln_bwd) adds the parameter gradient into the destination
  *   instead of overwriting it: the caller points it at the parameter's slot of a flat gradient arena, which
@@ -62,9 +63,14 @@ int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, i
 int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const void* res, const void* aux, void* y,
                  void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride,
                  int transposed, int act, int kblock, int dtype, void* stream);
+/* host-only: block tile (BM * 1000 + BN) mdm_conv_fwd will use for (M, Cout, dtype) -- for profiling labels */
+int mdm_conv_fwd_tile(int M, int Cout, int dtype);
+int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype);   /* 128 or 256 (square output tile edge) */
 int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes);
-int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, float* dbias, float* ws, int N, int H, int W,
-                   int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int accumulate, int dtype, void* stream);
+int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, float* ws, int N, int H, int W, int Cin, int Ho,
+                   int Wo, int Cout, int ksize, int stride, int dtype, void* stream);
+int mdm_conv_wgrad_reduce(const float* ws, float* dw_oihw, float* dbias, const void* dy, int M, int Cin, int Cout,
+                          int ksize, int accumulate, int dtype, void* stream);
 int mdm_colsum_plan(int M, int C, int* nblocks, size_t* ws_bytes);
 int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulate, int dtype, void* stream);
 

@@ -43,6 +43,16 @@ struct ConvArgs {
 
 enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };
 
+// 4 consecutive elements (8 / 16 bytes, aligned) -> fp32
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+  const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+}
+__device__ __forceinline__ void load4(const bf16* p, float (&o)[4]) {
+  const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+  o[0] = (float)t[0]; o[1] = (float)t[1]; o[2] = (float)t[2]; o[3] = (float)t[3];
+}
+
 // 16-byte-aligned zeros in device memory: the source of every out-of-range LDS-DMA chunk
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[4] = {};
 
@@ -294,12 +304,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
               } else if (p.act == 2) {
+                float a4[4];
+                load4(AUX + o, a4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(to_f32(AUX[o + e]));
+                for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(a4[e]);
               }
               if (R) {
+                float r4[4];
+                load4(R + o, r4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += to_f32(R[o + e]);
+                for (int e = 0; e < 4; ++e) v[e] += r4[e];
               }
             }
           }
@@ -1072,6 +1086,26 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
 
 static int g_big_tile = -1;   // MDM_HIP_BIGTILE=0 forces the 128x128 kernel (A/B testing)
 
+// block tile (BM * 1000 + BN) the forward / dgrad kernel uses for a problem
+static int conv_tile_code(int M, int Cout, int dtype) {
+  if (Cout <= 32) return 128032;
+  if (Cout <= 64) return 128064;
+  if (g_big_tile < 0) {
+    const char* e = getenv("MDM_HIP_BIGTILE");
+    g_big_tile = e ? atoi(e) : 2;
+  }
+  const long big_tiles = (long)((M + 255) / 256) * ((Cout + 127) / 128);
+  const long huge_tiles = (long)((M + 255) / 256) * ((Cout + 255) / 256);
+  if (dtype == DT_BF16 && g_big_tile == 2 && huge_tiles >= 256) {
+    const long waves = (huge_tiles + 255) / 256;
+    if (huge_tiles * 5 >= waves * 256 * 4) return 256256;
+  }
+  if (g_big_tile == 1 && big_tiles >= 256) return 256128;
+  return 128128;
+}
+
+extern "C" int mdm_conv_fwd_tile(int M, int Cout, int dtype) { return conv_tile_code(M, Cout, dtype); }
+
 template <typename T, int MODE>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE, 2>(a, st);
@@ -1146,6 +1180,8 @@ static int wgrad_tile(int M, int Cout, int K, int dtype) {
   return (dtype == DT_BF16 && g_wgrad_big && Cout >= 256 && K >= 256 && (K >= 2304 || M >= 65536)) ? 256 : 128;
 }
 
+extern "C" int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype) { return wgrad_tile(M, Cout, K, dtype); }
+
 extern "C" int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes) {
   MDM_CHECK_ARG(splits_out && ws_bytes);
   const int bkm = dtype == DT_F32 ? 32 : 64;
@@ -1173,10 +1209,9 @@ static void wgrad_set_smem(K kern, int bytes) {
 
 extern "C" int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulate, int dtype, void* stream);
 
-extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, float* dbias, float* ws, int N, int H,
-                              int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int accumulate,
-                              int dtype, void* stream) {
-  MDM_CHECK_ARG(x && dy && dw_oihw && ws);
+extern "C" int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, float* ws, int N, int H, int W, int Cin,
+                              int Ho, int Wo, int Cout, int ksize, int stride, int dtype, void* stream) {
+  MDM_CHECK_ARG(x && dy && ws);
   MDM_CHECK_ARG(ksize == 1 || ksize == 3);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
   const int epv = dtype == DT_F32 ? 4 : 8;
@@ -1192,7 +1227,7 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, flo
   const int mt_total = (a.M + bkm - 1) / bkm;
   a.mtiles_per_split = (mt_total + a.splits - 1) / a.splits;
   float* const bias_ws = ws + (size_t)a.splits * Cout * a.K;
-  a.bslab = (dbias && dtype == DT_BF16) ? bias_ws : nullptr;   // the bf16 kernels fold the column sums in
+  a.bslab = (want_bias && dtype == DT_BF16) ? bias_ws : nullptr;   // the bf16 kernels fold the column sums in
   const int te = wgrad_tile(a.M, Cout, a.K, dtype);
   const int tiles = ((Cout + te - 1) / te) * ((a.K + te - 1) / te);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1218,18 +1253,37 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, float* dw_oihw, flo
     if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_1x1, 0>), grid, dim3(256), smem, st, a);
     else hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_3x3, 0>), grid, dim3(256), smem, st, a);
   }
-  const int bblocks = a.bslab ? (Cout + 255) / 256 : 0;
+  MDM_LAUNCH_STATUS();
+}
+
+// Second half of the weight gradient: dw (Cout, Cin, k, k) (+)= sum over the split slabs written by mdm_conv_wgrad
+// (also converts the packed [o][tap][i] slab order to the reference OIHW layout), dbias (+)= bias partials.
+// Must be called with the same geometry / dtype / workspace right after mdm_conv_wgrad on the same stream.
+extern "C" int mdm_conv_wgrad_reduce(const float* ws, float* dw_oihw, float* dbias, const void* dy, int M, int Cin,
+                                     int Cout, int ksize, int accumulate, int dtype, void* stream) {
+  MDM_CHECK_ARG(ws && dw_oihw && (ksize == 1 || ksize == 3));
+  const int K = ksize * ksize * Cin;
+  int splits; size_t wsb;
+  int rc = mdm_conv_wgrad_plan(M, Cout, K, dtype, &splits, &wsb);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* const bias_ws = const_cast<float*>(ws) + (size_t)splits * Cout * K;
+  const float* bslab = (dbias && dtype == DT_BF16) ? bias_ws : nullptr;
+  const int bblocks = bslab ? (Cout + 255) / 256 : 0;
   if (ksize == 1) {
     const size_t total = (size_t)Cout * Cin;
     const int wblocks = (int)((total / 4 + 255) / 256 > 2048 ? 2048 : (total / 4 + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, ws, dw_oihw, a.bslab, dbias,
-                       a.splits, Cout, total, accumulate, wblocks);
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, ws, dw_oihw, bslab, dbias,
+                       splits, Cout, total, accumulate, wblocks);
   } else {
     const int wblocks = Cout * ((Cin + 63) / 64);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, ws, dw_oihw, a.bslab, dbias,
-                       a.splits, Cout, Cin, ksize * ksize, accumulate, wblocks);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, ws, dw_oihw, bslab, dbias,
+                       splits, Cout, Cin, ksize * ksize, accumulate, wblocks);
   }
-  if (dbias && !a.bslab) return mdm_colsum(dy, dbias, bias_ws, a.M, Cout, accumulate, dtype, stream);
+  if (dbias && !bslab) {
+    MDM_CHECK_ARG(dy);
+    return mdm_colsum(dy, dbias, bias_ws, M, Cout, accumulate, dtype, stream);
+  }
   MDM_LAUNCH_STATUS();
 }
 

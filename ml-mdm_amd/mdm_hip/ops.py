@@ -242,9 +242,9 @@ def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, 
 
     if _prof is None:
         return go()
-    tile = 32 if Cout <= 32 else (64 if Cout <= 64 else 128)
+    code = _lib.lib().mdm_conv_fwd_tile(N * Ho * Wo, Cout, _dt(x))
     mode = "1x1" if ks == 1 else ("3x3_T2" if transposed else "3x3")
-    name = "conv_gemm_kernel<%s,128x%d,%s>" % ("f32" if x.dtype == torch.float32 else "bf16", tile, mode)
+    name = "conv_gemm_kernel<%s,%dx%d,%s>" % ("f32" if x.dtype == torch.float32 else "bf16", code // 1000, code % 1000, mode)
     flops = 2.0 * N * Ho * Wo * Cout * ks * ks * Cin / (4 if transposed else 1)
     return _prof_wrap(name, flops, go)
 
@@ -261,15 +261,19 @@ def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride, out=None, dbias
     dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device) if out is None else out
 
     def go():
-        _lib.check(L.mdm_conv_wgrad(_p(x), _p(dy), _p(dw), _p(dbias), _p(ws), N, H, W, Cin, Ho, Wo, Cout, ks, stride,
-                                    0 if out is None else 1, _dt(x), _stream()),
+        _lib.check(L.mdm_conv_wgrad(_p(x), _p(dy), 0 if dbias is None else 1, _p(ws), N, H, W, Cin, Ho, Wo, Cout, ks, stride,
+                                    _dt(x), _stream()),
                    "mdm_conv_wgrad")
 
     if _prof is None:
         go()
     else:
-        name = "conv_wgrad_kernel<%s,%s>+reduce" % ("f32" if x.dtype == torch.float32 else "bf16", "1x1" if ks == 1 else "3x3")
+        te = L.mdm_conv_wgrad_tile(M, Cout, K, _dt(x))
+        kn = "conv_wgrad_kernel" if x.dtype == torch.float32 else "conv_wgrad_tr_kernel"
+        name = "%s<%s,%dx%d,%s>" % (kn, "f32" if x.dtype == torch.float32 else "bf16", te, te, "1x1" if ks == 1 else "3x3")
         _prof_wrap(name, 2.0 * M * Cout * K, go)
+    _lib.check(L.mdm_conv_wgrad_reduce(_p(ws), _p(dw), _p(dbias), _p(dy), M, Cin, Cout, ks, 0 if out is None else 1, _dt(x),
+                                       _stream()), "mdm_conv_wgrad_reduce")
     return dw
 
 
