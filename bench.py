@@ -168,7 +168,6 @@ def main():
     roof = None
     if not args.no_roofline and rank == 0:
         # one extra, untimed step with HIP events around every GEMM-class launch (on the launch stream)
-        ops.enable_async_wgrad(False)   # standalone kernel durations: no concurrent weight-gradient stream
         ops.profile_begin()
         step(sample)
         torch.cuda.synchronize()
