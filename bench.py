@@ -28,7 +28,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 # algorithmic forward matmul-class FLOPs per sample, measured on the reference (SURVEY.md section 8a/8d, S = 32)
-FWD_GFLOP_PER_SAMPLE = {"unet64": 363.9, "nested256": 589.1}
+FWD_GFLOP_PER_SAMPLE = {"unet64": 363.9, "nested256": 589.1, "mini": 0.0}
 PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_F32_TFLOPS = 157.3
 
@@ -44,6 +44,9 @@ def build(workload, device, seed=0):
     if workload == "unet64":
         net = mdm_hip.UNet(3, 3, configs.unet64_config(2048))
         pipe_cls, dcfg, side = diffusion.Diffusion, diffusion.DiffusionConfig(sampler_config=sc, use_vdm_loss_weights=False), 64
+    elif workload == "mini":  # development only (reduced architecture, not a reportable number)
+        net = mdm_hip.UNet(3, 3, configs.mini_unet_config(2048))
+        pipe_cls, dcfg, side = diffusion.Diffusion, diffusion.DiffusionConfig(sampler_config=sc, use_vdm_loss_weights=False), 16
     else:
         sc.schedule_shifted, sc.rescale_signal = True, 1
         net = mdm_hip.NestedUNet(3, 3, configs.nested256_config(2048))
@@ -106,7 +109,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="unet64", choices=["unet64", "nested256"])
+    ap.add_argument("--workload", default="unet64", choices=["unet64", "nested256", "mini"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 / 16)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,11 +122,15 @@ def main():
     from mdm_hip import ops
     from mdm_hip.trainer import TrainStep
 
-    local, rank, world = mdist.init_distributed_singlenode()
+    # MDM_DIST_BACKEND=gloo + MDM_BENCH_DEVICE=0 let two ranks share ONE GPU (development check of the N > 1 path
+    # on the single-GPU box); the driver's real runs use RCCL with one GPU per rank
+    local, rank, world = mdist.init_distributed_singlenode(backend=os.environ.get("MDM_DIST_BACKEND"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if "MDM_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["MDM_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    batch = args.batch or (64 if args.workload == "unet64" else 16)
+    batch = args.batch or {"unet64": 64, "nested256": 16, "mini": 4}[args.workload]
 
     pipe, side = build(args.workload, device)
     step = TrainStep(pipe, bf16=args.dtype == "bf16")

@@ -51,7 +51,6 @@ def init_distributed_singlenode(timeout: int = 0, backend: str = None):
     kw = {"timeout": timedelta(seconds=timeout)} if timeout else {}
     if backend == "nccl":
         torch.cuda.set_device(local)
-        kw["device_id"] = torch.device("cuda", local)
     dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank, **kw)
     dist.barrier()
     return local, rank, world
@@ -87,6 +86,7 @@ class GradReducer:
         for p in order:
             self._need[self._bucket_of[p]] += 1
         self._pending = list(self._need)
+        self._fired = {}
         self._work = []
         self._enabled = True
         if self.world > 1:
@@ -111,6 +111,11 @@ class GradReducer:
         if not self._enabled:
             return
         b = self._bucket_of[p]
+        if id(p) in self._fired:
+            # a parameter whose gradient went through the sink reports via ready(); autograd's post-accumulate hook
+            # may still fire for it (with an undefined gradient) -- count every parameter once per step
+            return
+        self._fired[id(p)] = 1
         self._pending[b] -= 1
         if self._pending[b] == 0:
             self._launch(b)
@@ -148,13 +153,16 @@ class GradReducer:
                 return  # no synchronised backward since the last finish()
             missing = [b for b, n in enumerate(self._pending) if n != 0]
             if missing:
-                raise RuntimeError("buckets %s did not receive all their gradients (unused parameters?)" % missing)
+                lost = [(i, tuple(p.shape), self._fired.get(id(p), 0)) for i, p in enumerate(self.params) if self._fired.get(id(p), 0) != 1]
+                raise RuntimeError("buckets %s did not receive all their gradients; parameters (index, shape) that "
+                                   "did not report exactly once (index, shape, count): %s" % (missing, lost[:12]))
             for h, buf, wire in self._work:
                 h.wait()
                 if wire is not None:
                     buf.copy_(wire)
             self._work = []
             self._pending = list(self._need)
+            self._fired = {}
 
     def zero_grad(self):
         self.flat.zero_()
