@@ -473,8 +473,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 //   S = Q K^T (rows = queries, permuted), dP = dO V^T, dS = P o (dP - delta)
 //   dV^T = dO^T P,  dK^T = Q^T dS
 // ---------------------------------------------------------------------------------------
-template <typename T, int D>
+template <typename T, int D, int KT>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+  // KT = 16-key tiles per wave: the block owns 64 * KT keys; the Q / dO fragments of a query tile are read from LDS
+  // once and reused for every key tile of the wave (KT = 2 halves the tile loads and LDS reads per key)
   using G = AttnGeom<T, D>;
   constexpr int KSTEPS = G::KSTEPS, DS = G::DS, DT = G::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -490,29 +492,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
   const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
   const int pass = p.pass;
   const int nk = pass ? p.S : p.L;
-  const int key = blockIdx.x * 64 + wave * 16 + l16;
 
   const T* Kp = reinterpret_cast<const T*>(pass ? p.kc : p.k) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
   const T* Vp = reinterpret_cast<const T*>(pass ? p.vc : p.v) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
   const int rs = pass ? p.c_rs : p.k_rs;
-  bool key_ok = key < nk;
-  Frag<T> kf[DS], vf[DS];
+  int key[KT];
+  bool key_ok[KT], key_live[KT];
+  Frag<T> kf[KT][DS], vf[KT][DS];
 #pragma unroll
-  for (int ks = 0; ks < DS; ++ks) {
-    frag_from_global<T>(kf[ks], Kp + (size_t)key * rs + ks * 32 + quad * 8, key_ok);
-    frag_from_global<T>(vf[ks], Vp + (size_t)key * rs + ks * 32 + quad * 8, key_ok);
+  for (int kk = 0; kk < KT; ++kk) {
+    key[kk] = blockIdx.x * (64 * KT) + wave * (16 * KT) + kk * 16 + l16;
+    key_ok[kk] = key[kk] < nk;
+#pragma unroll
+    for (int ks = 0; ks < DS; ++ks) {
+      frag_from_global<T>(kf[kk][ks], Kp + (size_t)key[kk] * rs + ks * 32 + quad * 8, key_ok[kk]);
+      frag_from_global<T>(vf[kk][ks], Vp + (size_t)key[kk] * rs + ks * 32 + quad * 8, key_ok[kk]);
+    }
+    key_live[kk] = key_ok[kk];
+    if (key_ok[kk] && pass && p.mask) key_live[kk] = p.mask[(size_t)b * p.S + key[kk]] != 0.f;
   }
-  bool key_live = key_ok;
-  if (key_ok && pass && p.mask) key_live = p.mask[(size_t)b * p.S + key] != 0.f;
 
   const T* Q = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * D;
   const T* DO = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.o_bs + (size_t)h * D;
   const float* LSE = (pass ? p.lse_cross : p.lse_self) + ((size_t)b * p.H + h) * p.L;
   const float* DEL = (pass ? p.delta_cross : p.delta_self) + ((size_t)b * p.H + h) * p.L;
 
-  f32x4 dk[DT], dv[DT];
+  f32x4 dk[KT][DT], dv[KT][DT];
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int kk = 0; kk < KT; ++kk)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dk[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   for (int q0 = 0; q0 < p.L; q0 += 64) {
     __syncthreads();
@@ -528,37 +537,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
       del_s[tid] = qi < p.L ? DEL[qi] : 0.f;
     }
     __syncthreads();
-    f32x4 s[4], dp[4];
+    f32x4 s[KT][4], dp[KT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const int row = perm_row(kt, l16);
-      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KT; ++kk) { s[kk][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kk][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < DS; ++ks) {
         Frag<T> a, g;
         load_frag<T>(a, Qs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
         load_frag<T>(g, Gs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
-        mma16(s[kt], a, kf[ks]);
-        mma16(dp[kt], g, vf[ks]);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+          mma16(s[kk][kt], a, kf[kk][ks]);
+          mma16(dp[kk][kt], g, vf[kk][ks]);
+        }
       }
     }
     // lane: key = l16 (column), query positions (kt>>1)*32 + quad*8 + (kt&1)*4 + i
-    f32x4 pr[4];
+    Frag<T> pf[KT][2], dsf[KT][2];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kk = 0; kk < KT; ++kk) {
+      f32x4 pr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int qp = (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
-        const float pv = key_live ? __expf(s[kt][i] * p.scale - lse_s[qp]) : 0.f;
-        pr[kt][i] = pv;
-        s[kt][i] = pv * (dp[kt][i] - del_s[qp]);
-      }
-    Frag<T> pf[2], dsf[2];
-    frag_from_acc<T>(pf[0], pr[0], pr[1]);
-    frag_from_acc<T>(pf[1], pr[2], pr[3]);
-    frag_from_acc<T>(dsf[0], s[0], s[1]);
-    frag_from_acc<T>(dsf[1], s[2], s[3]);
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int qp = (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
+          const float pv = key_live[kk] ? __expf(s[kk][kt][i] * p.scale - lse_s[qp]) : 0.f;
+          pr[kt][i] = pv;
+          s[kk][kt][i] = pv * (dp[kk][kt][i] - del_s[qp]);
+        }
+      frag_from_acc<T>(pf[kk][0], pr[0], pr[1]);
+      frag_from_acc<T>(pf[kk][1], pr[2], pr[3]);
+      frag_from_acc<T>(dsf[kk][0], s[kk][0], s[kk][1]);
+      frag_from_acc<T>(dsf[kk][1], s[kk][2], s[kk][3]);
+    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -566,19 +581,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         Frag<T> a, g;
         load_frag_T<T, D>(g, Gs, GTs, dt, hh, quad, l16);
         load_frag_T<T, D>(a, Qs, QTs, dt, hh, quad, l16);
-        mma16(dv[dt], g, pf[hh]);
-        mma16(dk[dt], a, dsf[hh]);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+          mma16(dv[kk][dt], g, pf[kk][hh]);
+          mma16(dk[kk][dt], a, dsf[kk][hh]);
+        }
       }
   }
-  if (key_ok) {
-    T* DK = reinterpret_cast<T*>(p.dk) + (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key * p.dk_rs;
-    T* DV = reinterpret_cast<T*>(p.dv) + (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key * p.dk_rs;
+#pragma unroll
+  for (int kk = 0; kk < KT; ++kk) {
+    if (!key_ok[kk]) continue;
+    T* DK = reinterpret_cast<T*>(p.dk) + (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key[kk] * p.dk_rs;
+    T* DV = reinterpret_cast<T*>(p.dv) + (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key[kk] * p.dk_rs;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        DK[dt * 16 + quad * 4 + i] = from_f32<T>(dk[dt][i] * p.scale);
-        DV[dt * 16 + quad * 4 + i] = from_f32<T>(dv[dt][i]);
+        DK[dt * 16 + quad * 4 + i] = from_f32<T>(dk[kk][dt][i] * p.scale);
+        DV[dt * 16 + quad * 4 + i] = from_f32<T>(dv[kk][dt][i]);
       }
   }
 }
@@ -612,12 +632,15 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
   constexpr int smem_q = 2 * G::NAT_BYTES + G::TR_BYTES;
   constexpr int smem_kv = 2 * G::NAT_BYTES + 2 * G::TR_BYTES + 512;
   auto kq = attn_bwd_dq_kernel<T, D, QT>;
-  auto kkv = attn_bwd_dkv_kernel<T, D>;
+  auto kkv = attn_bwd_dkv_kernel<T, D, 1>;
+  constexpr int KTS = 1;   // 2 key tiles per wave measured SLOWER (286-331 registers -> 1 wave / SIMD): 2.18 vs 1.59 ms
+  auto kkv2 = attn_bwd_dkv_kernel<T, D, KTS>;
   static bool done = false;
-  if (!done) { set_smem(kq, smem_q); set_smem(kkv, smem_kv); done = true; }
+  if (!done) { set_smem(kq, smem_q); set_smem(kkv, smem_kv); set_smem(kkv2, smem_kv); done = true; }
   hipLaunchKernelGGL(kq, dim3((a.L + 64 * QT - 1) / (64 * QT), a.B * a.H), dim3(256), smem_q, st, a);
   a.pass = 0;
-  hipLaunchKernelGGL(kkv, dim3((a.L + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);
+  if (a.L >= 128) hipLaunchKernelGGL(kkv2, dim3((a.L + 64 * KTS - 1) / (64 * KTS), a.B * a.H), dim3(256), smem_kv, st, a);
+  else hipLaunchKernelGGL(kkv, dim3((a.L + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);
   if (a.kc) {
     a.pass = 1; a.dk = dkc; a.dv = dvc; a.dk_bs = dc_bs; a.dk_rs = dc_rs;
     hipLaunchKernelGGL(kkv, dim3((a.S + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);
