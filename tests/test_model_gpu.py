@@ -190,3 +190,52 @@ def test_weights_are_repacked_after_an_optimizer_step():
     _, cfg, _ = PC.build_module("mini_unet")
     y_ref = O.model_forward(sd, cfg, inp["x"], inp["times"], inp["cond"], inp["mask"])
     assert O.rel_l2(y1.cpu(), y_ref) < 1e-4             # ... and it is exactly the updated parameters
+
+
+@pytest.mark.parametrize("which", ["unet64", "nested256"])
+def test_full_size_architectures_match_oracle(which):
+    """BASELINE.json configs[1]/[2] architectures at FULL size (461 M / 477 M parameters), batch 1, fp32 mode:
+    forward output (and, for UNet-64, every parameter gradient) of the HIP path vs the CPU oracle on the same
+    seeded weights.  Also a size-independent property: the bf16 run of the same input stays within the bf16 gate."""
+    import mdm_hip
+    from mdm_hip import configs
+
+    torch.manual_seed(0)
+    if which == "unet64":
+        cfg_fn, cls, side = (lambda: configs.unet64_config(2048)), mdm_hip.UNet, 64
+    else:
+        cfg_fn, cls, side = (lambda: configs.nested256_config(2048)), mdm_hip.NestedUNet, 256
+    model = cls(3, 3, cfg_fn())
+    sd = O.randomize_zero_params(model.state_dict(), seed=99)
+    model.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 3, side, side, generator=g)
+    xs = [x, torch.randn(1, 3, 64, 64, generator=g)] if which == "nested256" else x
+    cond, mask, times = torch.randn(1, 32, 2048, generator=g), torch.ones(1, 32), torch.tensor([417])
+    gys = [torch.randn(t.shape, generator=g) for t in PC.as_list(xs)]
+    with_grad = which == "unet64"
+
+    leaf = {k: v.clone().requires_grad_(with_grad) for k, v in sd.items()}
+    o_ref = PC.as_list(O.model_forward(leaf, cfg_fn(), xs, times, cond, mask))
+    if with_grad:
+        PC.loss_of(o_ref, gys).backward()
+    o_ref = [o.detach() for o in o_ref]
+
+    model = model.cuda()
+    xs_d = [t.cuda() for t in xs] if isinstance(xs, list) else xs.cuda()
+    if with_grad:
+        out = PC.as_list(model(xs_d, times.cuda(), cond.cuda(), mask.cuda()))
+        PC.loss_of(out, gys).backward()
+    else:
+        with torch.no_grad():
+            out = PC.as_list(model(xs_d, times.cuda(), cond.cuda(), mask.cuda()))
+    for a, b in zip(out, o_ref):
+        assert O.rel_l2(a.float().cpu(), b) < 1e-4
+    if with_grad:
+        errs, _ = PC.grad_errors({k: p.grad for k, p in model.named_parameters()}, {k: v.grad for k, v in leaf.items()})
+        worst = max((e, k) for k, e in errs.items())
+        assert worst[0] < 2e-3, worst
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out16 = PC.as_list(model(xs_d, times.cuda(), cond.cuda(), mask.cuda()))
+    for a, b in zip(out16, o_ref):
+        assert O.rel_l2(a.float().cpu(), b) < 3e-2
