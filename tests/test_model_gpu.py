@@ -239,3 +239,27 @@ def test_full_size_architectures_match_oracle(which):
         out16 = PC.as_list(model(xs_d, times.cuda(), cond.cuda(), mask.cuda()))
     for a, b in zip(out16, o_ref):
         assert O.rel_l2(a.float().cpu(), b) < 3e-2
+
+
+@pytest.mark.parametrize("name", ["mini_unet", "mini_nested"])
+def test_graph_replay_matches_eager(name):
+    """GraphedDenoiser: hipGraph replay of the forward == eager forward, bit for bit, also after the inputs change"""
+    from mdm_hip.graph import GraphedDenoiser
+
+    model, _, _ = PC.build_module(name)
+    model = model.cuda().eval()
+    graphed = GraphedDenoiser(model)
+    inp = PC.inputs(name)
+    to_dev = lambda v: [t.cuda() for t in v] if isinstance(v, list) else v.cuda()
+    with torch.no_grad():
+        for shift in (0.0, 0.37):
+            x = inp["x"]
+            x = [t + shift for t in x] if isinstance(x, list) else x + shift
+            times = inp["times"] - int(shift * 10)
+            args = (to_dev(x), times.cuda(), inp["cond"].cuda() * (1 + shift), inp["mask"].cuda())
+            eager = PC.as_list(model(*args))
+            replay = PC.as_list(graphed(*args))
+            for a, b in zip(eager, replay):
+                assert torch.equal(a, b)
+    assert len(graphed._graphs) == 1
+    assert graphed.input_channels == 3
