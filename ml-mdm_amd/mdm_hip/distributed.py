@@ -87,6 +87,7 @@ class GradReducer:
             self._need[self._bucket_of[p]] += 1
         self._pending = list(self._need)
         self._fired = {}
+        self._streams = [set() for _ in self.buckets]
         self._work = []
         self._enabled = True
         if self.world > 1:
@@ -116,8 +117,18 @@ class GradReducer:
             # may still fire for it (with an undefined gradient) -- count every parameter once per step
             return
         self._fired[id(p)] = 1
+        if p.is_cuda:
+            # gradients of one bucket are produced on several HIP streams (main backward chain, weight-gradient side
+            # stream): remember them so the all-reduce can be ordered after every producer
+            self._streams[b].add(torch.cuda.current_stream())
         self._pending[b] -= 1
         if self._pending[b] == 0:
+            if p.is_cuda:
+                cur = torch.cuda.current_stream()
+                for st in self._streams[b]:
+                    if st != cur:
+                        cur.wait_stream(st)
+                self._streams[b] = set()
             self._launch(b)
 
     def _launch(self, b):
