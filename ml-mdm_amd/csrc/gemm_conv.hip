@@ -20,6 +20,8 @@
 // ends up with 4 consecutive output channels of one pixel -> vector stores.
 #include <stdlib.h>
 
+#include <utility>
+
 #include "common.hpp"
 
 namespace mdm {
@@ -39,6 +41,7 @@ struct ConvArgs {
   int act;            // 0 none, 1 y=gelu(v), 2 y=v*gelu'(aux)
   int kblk;           // 3x3 k-order: 0 = tap-major (k = tap*Cin + cin); B = channel-block-major,
                       // k = (cin / B) * 9 * B + tap * B + cin % B with B = the k-tile (64 bf16 / 32 fp32)
+  int dbg;            // development ablations (MDM_HIP_GEMM_DBG): 1 = no DMA after tile 0, 2 = no MFMA phase; 0 in production
 };
 
 enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };
@@ -56,6 +59,114 @@ __device__ __forceinline__ void load4(const bf16* p, float (&o)[4]) {
 // 16-byte-aligned zeros in device memory: the source of every out-of-range LDS-DMA chunk
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[4] = {};
 
+// Epilogue shared by the GEMM kernels: bias / activation / residual in registers (fp32), then the finished tile is
+// staged through LDS (free after the k-loop, LDS_BYTES of it) so that HBM sees whole 16-byte chunks of complete
+// output rows instead of the 8-byte-per-lane fragments of the MFMA layout.
+template <typename T, int BM, int BN, int WM, int WN, int LDS_BYTES>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
+                                              int m0, int n0) {
+  constexpr int EPV = Tr<T>::EPV;
+  constexpr int NT_ = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MT = TM / 16, NT = TN / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int quad = lane >> 4, l16 = lane & 15;
+  // bias / activation / residual are applied in registers (fp32); the finished tile is then staged through
+  // LDS (free after the k-loop) so that HBM sees whole 16-byte chunks of complete output rows instead of the
+  // 8-byte-per-lane fragments of the MFMA layout (the output-heavy 1x1 convs -- qkv, FFN up -- were store-bound).
+  T* __restrict__ Y = reinterpret_cast<T*>(p.y);
+  T* __restrict__ Ypre = reinterpret_cast<T*>(p.ypre);
+  const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
+  const T* __restrict__ AUX = reinterpret_cast<const T*>(p.aux);
+  constexpr int PITCH = (sizeof(T) == 2 && BM * (BN * 2 + 16) <= LDS_BYTES) ? BN * 2 + 16 : BN * (int)sizeof(T);   // bytes per staged row
+  static_assert(BM * PITCH <= LDS_BYTES, "output tile must fit the k-loop LDS");
+  constexpr int OCH = BN / EPV;                                    // 16-byte chunks per staged row
+  if ((p.Cout % EPV) == 0) {
+    const int first_pass = (p.act == 1 && Ypre) ? 0 : 1;
+    for (int pass = first_pass; pass < 2; ++pass) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int ml = wm * TM + i * 16 + l16, m = m0 + ml;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int nl = wn * TN + j * 16 + quad * 4, n = n0 + nl;
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          const bool live = m < p.M && n < p.Cout;   // Cout % 4 == 0 here: all four or none
+          if (live) {
+            const size_t o = (size_t)m * p.Cout + n;
+            if (p.bias) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bv[e];
+            }
+            if (pass == 1) {
+              if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+              } else if (p.act == 2) {
+                float a4[4];
+                load4(AUX + o, a4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(a4[e]);
+              }
+              if (R) {
+                float r4[4];
+                load4(R + o, r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+              }
+            }
+          }
+          char* dst = smem + ml * PITCH + nl * (int)sizeof(T);
+          if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+          } else {
+            *reinterpret_cast<bf16x4*>(dst) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          }
+        }
+      }
+      __syncthreads();
+      T* __restrict__ OUT = pass == 0 ? Ypre : Y;
+      for (int idx = tid; idx < BM * OCH; idx += NT_) {
+        const int row = idx / OCH, ch = idx - row * OCH;
+        const int m = m0 + row, n = n0 + ch * EPV;
+        if (m < p.M && n < p.Cout)
+          *reinterpret_cast<uint4*>(OUT + (size_t)m * p.Cout + n) = *reinterpret_cast<const uint4*>(smem + row * PITCH + ch * 16);
+      }
+      if (pass == 0) __syncthreads();
+    }
+    return;
+  }
+  // generic path (Cout not a multiple of the chunk): per-element stores
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * TM + i * 16 + l16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * TN + j * 16 + quad * 4;
+      if (n >= p.Cout) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const size_t o = (size_t)m * p.Cout + n;
+      const int nv = min(4, p.Cout - n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (e >= nv) continue;
+        if (p.bias) v[e] += p.bias[n + e];
+        if (p.act == 1) {
+          if (Ypre) Ypre[o + e] = from_f32<T>(v[e]);
+          v[e] = gelu_f(v[e]);
+        } else if (p.act == 2) {
+          v[e] *= dgelu_f(to_f32(AUX[o + e]));
+        }
+        if (R) v[e] += to_f32(R[o + e]);
+        Y[o + e] = from_f32<T>(v[e]);
+      }
+    }
+  }
+}
+
 // NSTAGE = 2: 4-wave block, next tile's DMA overlaps this tile's MFMAs, __syncthreads() drains it (vmcnt(0)).
 // NSTAGE = 3: 8-wave block (256-row tile), DMA runs TWO tiles ahead; a counted s_waitcnt vmcnt(loads per tile) +
 //             raw s_barrier retires only the tile needed next, so loads stay in flight across the barrier
@@ -65,7 +176,7 @@ __device__ __attribute__((aligned(16))) uint4 g_zero_page[4] = {};
 //     raw s_barrier after every segment, so the matrix pipe always has exactly one wave feeding it instead of
 //     both waves loading together and then fighting for the pipe.
 template <typename T, int BM, int BN, int WM, int WN, int MODE, int NSTAGE, bool PP = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(ConvArgs p) {
   constexpr int EPV = Tr<T>::EPV, BK = Tr<T>::BK, KSTEPS = Tr<T>::KSTEPS;
   constexpr int NT_ = WM * WN * 64;                  // threads per block
   constexpr int RPP = NT_ / 8;                       // tile rows staged per pass (8 chunk lanes per row)
@@ -243,8 +354,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(ConvArgs p) {
     __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
       char* cur = smem + (kt & 1) * STAGE;
-      if (kt + 1 < ntiles) MDM_STAGE_TILE(smem + ((kt + 1) & 1) * STAGE);
-      MDM_COMPUTE_TILE(cur);
+      if (kt + 1 < ntiles && !(p.dbg & 1)) MDM_STAGE_TILE(smem + ((kt + 1) & 1) * STAGE);
+      if (!(p.dbg & 2)) MDM_COMPUTE_TILE(cur);
       __syncthreads();   // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
     }
   } else {
@@ -270,100 +381,195 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(ConvArgs p) {
 #undef MDM_STAGE_TILE
 #undef MDM_GLDS
 
-  // ---- epilogue -------------------------------------------------------------
-  // bias / activation / residual are applied in registers (fp32); the finished tile is then staged through
-  // LDS (free after the k-loop) so that HBM sees whole 16-byte chunks of complete output rows instead of the
-  // 8-byte-per-lane fragments of the MFMA layout (the output-heavy 1x1 convs -- qkv, FFN up -- were store-bound).
-  T* __restrict__ Y = reinterpret_cast<T*>(p.y);
-  T* __restrict__ Ypre = reinterpret_cast<T*>(p.ypre);
-  const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
-  const T* __restrict__ AUX = reinterpret_cast<const T*>(p.aux);
-  constexpr int PITCH = (sizeof(T) == 2 && BM * (BN * 2 + 16) <= NSTAGE * STAGE) ? BN * 2 + 16 : BN * (int)sizeof(T);   // bytes per staged row
-  static_assert(BM * PITCH <= NSTAGE * STAGE, "output tile must fit the k-loop LDS");
-  constexpr int OCH = BN / EPV;                                    // 16-byte chunks per staged row
-  if ((p.Cout % EPV) == 0) {
-    const int first_pass = (p.act == 1 && Ypre) ? 0 : 1;
-    for (int pass = first_pass; pass < 2; ++pass) {
+  conv_epilogue<T, BM, BN, WM, WN, NSTAGE * STAGE>(p, acc, smem, m0, n0);
+}
+
+// ---------------------------------------------------------------------------
+// bf16 main-path kernel: same tiling / LDS image / epilogue as conv_gemm_kernel, different k-loop.
+//
+// In conv_gemm_kernel every k-tile opens with a block of ~70 VALU + 8 LDS-DMA issues per lane that computes the
+// implicit-GEMM gather addresses (64-bit, halo tests, zero-page select) -- with all eight waves of the block in
+// lock-step behind the per-tile barrier the matrix pipe idles through it (measured: k-loop without the staging
+// block 1.42 PF, staging alone 1.77 PF-equivalent, both 0.97 PF).  Here the gather is expressed as a buffer
+// address: a per-lane 32-bit byte offset fixed for the whole k-loop (row of the virtual im2col matrix, swizzled
+// 16-byte chunk) plus a wave-uniform SGPR offset per k-tile (tap shift + channel block), so a k-tile costs 8
+// `buffer_load_dwordx4 ... lds` whose only vector work is the halo select (a 9-bit tap mask per row, 3x3 only).
+// Rows / taps outside the image use an offset beyond num_records: the buffer range check returns zeros without a
+// memory access.  The 8 DMA issues and the second k-step's fragment reads are interleaved with the first k-step's
+// MFMAs (sched_group_barrier), so the load phase runs in the shadow of the matrix pipe.
+// Requirements (host-checked, else conv_gemm_kernel): bf16, 1x1 or channel-block-major 3x3 (s1 / s2),
+// K % 64 == 0, operands < 0x7F000000 bytes.
+// ---------------------------------------------------------------------------
+// issue pattern of a phase: per MFMA row, NT MFMAs, DMA LDS-DMA issues, one fragment read (literal arguments only)
+template <int NT, int DMA, int... I>
+__device__ __forceinline__ void sched_rows(std::integer_sequence<int, I...>) {
+  ((__builtin_amdgcn_sched_group_barrier(0x008, NT, I * 0), __builtin_amdgcn_sched_group_barrier(0x010, DMA, 0),
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)), ...);
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type has no host-side counterpart: the host pass only needs the stub
+  using T = bf16;
+  constexpr int NT_ = WM * WN * 64;
+  constexpr int RPP = NT_ / 8;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MT = TM / 16, NT = TN / 16;
+  constexpr int AJ = BM / RPP, BJ = BN / RPP;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr unsigned INVALID = 0x7F000000u;
+  static_assert(MODE == MODE_1x1 || MODE == MODE_3x3, "buffer-addressed loader: 1x1 and 3x3 only");
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int quad = lane >> 4, l16 = lane & 15;
+
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+
+  // ---- per-lane gather offsets (bytes), fixed for the whole k-loop -------------
+  const int lrow = tid >> 3;
+  const int lchunk = (tid & 7) ^ (lrow & 7);   // logical chunk this lane fetches (physical slot = tid & 7)
+  const unsigned bias = MODE == MODE_3x3 ? (unsigned)(p.W + 1) * p.Cin * 2u : 0u;   // base shift that keeps the per-tap scalar offset non-negative
+  unsigned a_voff[AJ], a_mask[AJ], b_voff[BJ];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int ml = wm * TM + i * 16 + l16, m = m0 + ml;
+  for (int j = 0; j < AJ; ++j) {
+    const int m = m0 + lrow + RPP * j;
+    a_voff[j] = INVALID; a_mask[j] = 0u;
+    if (m < p.M) {
+      if (MODE == MODE_1x1) {
+        a_voff[j] = (unsigned)m * p.Cin * 2u + lchunk * 16u;
+        a_mask[j] = 0x1ffu;
+      } else {
+        const int hw = p.Ho * p.Wo;
+        const int n = m / hw, r = m - n * hw;
+        const int oh = r / p.Wo, ow = r - oh * p.Wo;
+        const int ih0 = oh * p.stride, iw0 = ow * p.stride;
+        a_voff[j] = (unsigned)(n * p.H * p.W + ih0 * p.W + iw0) * p.Cin * 2u + lchunk * 16u;   // relative to a_base = x - bias
+        unsigned mk = 0u;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int nl = wn * TN + j * 16 + quad * 4, n = n0 + nl;
-          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          const bool live = m < p.M && n < p.Cout;   // Cout % 4 == 0 here: all four or none
-          if (live) {
-            const size_t o = (size_t)m * p.Cout + n;
-            if (p.bias) {
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += bv[e];
-            }
-            if (pass == 1) {
-              if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-              } else if (p.act == 2) {
-                float a4[4];
-                load4(AUX + o, a4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(a4[e]);
-              }
-              if (R) {
-                float r4[4];
-                load4(R + o, r4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += r4[e];
-              }
-            }
-          }
-          char* dst = smem + ml * PITCH + nl * (int)sizeof(T);
-          if constexpr (sizeof(T) == 4) {
-            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-          } else {
-            *reinterpret_cast<bf16x4*>(dst) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          }
+        for (int tp = 0; tp < 9; ++tp) {
+          const int ih = ih0 + tp / 3 - 1, iw = iw0 + tp % 3 - 1;
+          if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mk |= 1u << tp;
         }
-      }
-      __syncthreads();
-      T* __restrict__ OUT = pass == 0 ? Ypre : Y;
-      for (int idx = tid; idx < BM * OCH; idx += NT_) {
-        const int row = idx / OCH, ch = idx - row * OCH;
-        const int m = m0 + row, n = n0 + ch * EPV;
-        if (m < p.M && n < p.Cout)
-          *reinterpret_cast<uint4*>(OUT + (size_t)m * p.Cout + n) = *reinterpret_cast<const uint4*>(smem + row * PITCH + ch * 16);
-      }
-      if (pass == 0) __syncthreads();
-    }
-    return;
-  }
-  // generic path (Cout not a multiple of the chunk): per-element stores
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * TM + i * 16 + l16;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * TN + j * 16 + quad * 4;
-      if (n >= p.Cout) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const size_t o = (size_t)m * p.Cout + n;
-      const int nv = min(4, p.Cout - n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (e >= nv) continue;
-        if (p.bias) v[e] += p.bias[n + e];
-        if (p.act == 1) {
-          if (Ypre) Ypre[o + e] = from_f32<T>(v[e]);
-          v[e] = gelu_f(v[e]);
-        } else if (p.act == 2) {
-          v[e] *= dgelu_f(to_f32(AUX[o + e]));
-        }
-        if (R) v[e] += to_f32(R[o + e]);
-        Y[o + e] = from_f32<T>(v[e]);
+        a_mask[j] = mk;
       }
     }
   }
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int n = n0 + lrow + RPP * j;
+    b_voff[j] = n < p.Cout ? (unsigned)n * p.K * 2u + lchunk * 16u : INVALID;
+  }
+  const unsigned a_bytes = (unsigned)p.N * p.H * p.W * p.Cin * 2u + bias;
+  const unsigned b_bytes = (unsigned)p.Cout * p.K * 2u;
+  char* const a_base = const_cast<char*>(reinterpret_cast<const char*>(p.x)) - bias;
+  char* const b_base = const_cast<char*>(reinterpret_cast<const char*>(p.w));
+  const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
+  const int ntiles = p.K / 64;
+
+#define MDM_BLDS(rs, lds_off, voff, soff)                                                                   \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds_off), 16, voff, soff, 0, 0)
+  // Per-k-tile wave-uniform state of the loader: buffer descriptors (empty past the last tile, so the same loads
+  // fetch nothing), the A-side scalar offset (tap shift + channel block) and the tap's bit in the halo masks.
+#define MDM_TILE_STATE(kt_)                                                                                 \
+  const bool more_ = (kt_) < ntiles;                                                                        \
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(a_base, 0, more_ ? a_bytes : 0u, 0x00020000);         \
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(b_base, 0, more_ ? b_bytes : 0u, 0x00020000);         \
+  const int b_soff = (kt_) * 128;                                                                           \
+  int a_soff = b_soff, tapbit = 1;                                                                          \
+  if (MODE == MODE_3x3) {                                                                                   \
+    const int cb = (kt_) / 9, tap = (kt_) - 9 * cb;                                                         \
+    const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;                                                      \
+    a_soff = (kh * p.W + kw) * p.Cin * 2 + cb * 128;                                                        \
+    tapbit = 1 << tap;                                                                                      \
+  }
+  // piece q of a k-tile's AJ + BJ LDS-DMA issues (1 KiB per wave each)
+#define MDM_DMA_PIECE(stage, q)                                                                             \
+  if ((q) < AJ) {                                                                                           \
+    const unsigned vo = (MODE == MODE_1x1 || (a_mask[(q)] & tapbit)) ? a_voff[(q)] : INVALID;               \
+    MDM_BLDS(rsA, (stage) + (q) * (RPP * 128) + wave_lds, vo, a_soff);                                      \
+  } else if ((q) < AJ + BJ) {                                                                               \
+    MDM_BLDS(rsB, (stage) + A_BYTES + ((q) - AJ) * (RPP * 128) + wave_lds, b_voff[(q) - AJ], b_soff);       \
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Pipeline (one barrier per k-tile, in the middle of it):
+  //   phase A(kt): MFMAs of k-step 0 of tile kt; under them the fragment reads of k-step 1 (row i's A fragment is
+  //                re-loaded right after row i's MFMAs, B fragments double-buffered)
+  //   barrier    : every wave has issued all its LDS reads of tile kt; the DMA of tile kt+1 has landed
+  //   phase B(kt): MFMAs of k-step 1; under them the DMA of tile kt+2 into tile kt's buffer and the fragment
+  //                reads of k-step 0 of tile kt+1
+  // so neither the fragment reads nor the DMA issue ever run with the matrix pipe idle.
+  {
+    MDM_TILE_STATE(0);
+#pragma unroll
+    for (int q = 0; q < AJ + BJ; ++q) { MDM_DMA_PIECE(smem, q); }
+  }
+  {
+    MDM_TILE_STATE(1);
+#pragma unroll
+    for (int q = 0; q < AJ + BJ; ++q) { MDM_DMA_PIECE(smem + STAGE, q); }
+  }
+  __syncthreads();
+  Frag<T> af[MT], b0[NT], b1[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) load_frag<T>(b0[j], smem + A_BYTES, wn * TN + j * 16 + l16, 0, quad);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) load_frag<T>(af[i], smem, wm * TM + i * 16 + l16, 0, quad);
+  constexpr int DMA_PER_ROW = (AJ + BJ + MT - 1) / MT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const char* As = smem + (kt & 1) * STAGE;
+    const char* Bs = As + A_BYTES;
+    // ---- phase A
+#pragma unroll
+    for (int j = 0; j < NT; ++j) load_frag<T>(b1[j], Bs, wn * TN + j * 16 + l16, 1, quad);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) mma16(acc[i][j], b0[j], af[i]);
+      load_frag<T>(af[i], As, wm * TM + i * 16 + l16, 1, quad);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+    sched_rows<NT, 0>(std::make_integer_sequence<int, MT>{});
+    __builtin_amdgcn_sched_barrier(0);
+    // hipcc does not count the loop-carried LDS-DMA of the previous phase B at this barrier: retire it explicitly
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase B
+    const char* An = smem + ((kt + 1) & 1) * STAGE;
+    const char* Bn = An + A_BYTES;
+    char* dst = smem + (kt & 1) * STAGE;
+    MDM_TILE_STATE(kt + 2);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) load_frag<T>(b0[j], Bn, wn * TN + j * 16 + l16, 0, quad);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) mma16(acc[i][j], b1[j], af[i]);
+#pragma unroll
+      for (int d = 0; d < DMA_PER_ROW; ++d) { MDM_DMA_PIECE(dst, i * DMA_PER_ROW + d); }
+      load_frag<T>(af[i], An, wm * TM + i * 16 + l16, 0, quad);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+    sched_rows<NT, DMA_PER_ROW>(std::make_integer_sequence<int, MT>{});
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();   // LDS is reused by the epilogue
+#undef MDM_DMA_PIECE
+#undef MDM_TILE_STATE
+#undef MDM_BLDS
+  conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE>(p, acc, smem, m0, n0);
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1126,6 +1332,34 @@ static int conv_tile_code(int M, int Cout, int dtype) {
 
 extern "C" int mdm_conv_fwd_tile(int M, int Cout, int dtype) { return conv_tile_code(M, Cout, dtype); }
 
+template <int BM, int BN, int WM, int WN, int MODE>
+static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
+  constexpr int smem = 2 * (BM + BN) * 128;
+  auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_done = true;
+  }
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), smem, st, a);
+  MDM_LAUNCH_STATUS();
+}
+
+static int g_bl = -1;   // MDM_HIP_BLGEMM=0 falls back to the flat-address loader everywhere (A/B testing)
+
+// buffer-addressed k-loop (conv_gemm_bl_kernel) usable for this problem?
+template <typename T, int MODE>
+static bool conv_bl_ok(const ConvArgs& a) {
+  if (g_bl < 0) { const char* e = getenv("MDM_HIP_BLGEMM"); g_bl = e ? atoi(e) : 1; }
+  if (!g_bl || sizeof(T) != 2 || MODE == MODE_3x3_T2 || a.dbg) return false;
+  if (a.K % 64 != 0 || (MODE == MODE_3x3 && a.kblk == 0)) return false;
+  const size_t lim = 0x7F000000u;
+  const size_t bias = MODE == MODE_3x3 ? (size_t)(a.W + 1) * a.Cin * 2 : 0;
+  if ((size_t)a.N * a.H * a.W * a.Cin * 2 + bias > lim || (size_t)a.Cout * a.K * 2 > lim) return false;
+  return 2 * bias + (size_t)a.K * 2 < 0x00F00000u;   // INVALID + any tile offset stays below 2^31
+}
+
 template <typename T, int MODE>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE, 2>(a, st);
@@ -1146,11 +1380,13 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
       if (huge_tiles * 5 >= waves * 256 * 4) {
         static int pp = -1;
         if (pp < 0) { const char* e = getenv("MDM_HIP_PINGPONG"); pp = e ? atoi(e) : 0; }   // measured equal to the plain schedule; off by default
+        if constexpr (MODE != MODE_3x3_T2) { if (conv_bl_ok<T, MODE>(a)) return launch_conv_bl<256, 256, 2, 4, MODE>(a, st); }
         return pp ? launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2, true>(a, st) : launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2, false>(a, st);
       }
     }
   }
   if (g_big_tile == 1 && big_tiles >= 256) return launch_conv_cfg<T, 256, 128, 4, 2, MODE, 3>(a, st);
+  if constexpr (sizeof(T) == 2 && MODE != MODE_3x3_T2) { if (conv_bl_ok<T, MODE>(a)) return launch_conv_bl<128, 128, 2, 2, MODE>(a, st); }
   return launch_conv_cfg<T, 128, 128, 2, 2, MODE, 2>(a, st);
 }
 
@@ -1183,6 +1419,9 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
   const int bk = dtype == DT_F32 ? 32 : 64;
   MDM_CHECK_ARG(kblock == 0 || (ksize == 3 && kblock == bk && Cin % bk == 0));
   a.kblk = kblock;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("MDM_HIP_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+  a.dbg = dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return dtype == DT_F32 ? launch_conv_t<float>(a, ksize, transposed, st) : launch_conv_t<bf16>(a, ksize, transposed, st);
 }

@@ -9,6 +9,7 @@ Parameters stay fp32 in the reference's layout; packed copies for the kernels
 are cached per parameter version.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -184,6 +185,7 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
 # optional per-launch timing of the GEMM-class kernels (bench.py roofline leg)
 # --------------------------------------------------------------------------------------
 _prof = None
+_prof_shapes = os.environ.get("MDM_HIP_PROF_SHAPES", "0") == "1"   # development: key the table by GEMM shape as well
 
 
 def profile_begin():
@@ -246,6 +248,8 @@ def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, 
     mode = "1x1" if ks == 1 else ("3x3_T2" if transposed else "3x3")
     name = "conv_gemm_kernel<%s,%dx%d,%s>" % ("f32" if x.dtype == torch.float32 else "bf16", code // 1000, code % 1000, mode)
     flops = 2.0 * N * Ho * Wo * Cout * ks * ks * Cin / (4 if transposed else 1)
+    if _prof_shapes:
+        name += " M=%d N=%d K=%d" % (N * Ho * Wo, Cout, ks * ks * Cin)
     return _prof_wrap(name, flops, go)
 
 
@@ -271,6 +275,8 @@ def _wgrad_launch(x, dy, N, H, W, Cin, Ho, Wo, Cout, ks, stride, out=None, dbias
         te = L.mdm_conv_wgrad_tile(M, Cout, K, _dt(x))
         kn = "conv_wgrad_kernel" if x.dtype == torch.float32 else "conv_wgrad_tr_kernel"
         name = "%s<%s,%dx%d,%s>" % (kn, "f32" if x.dtype == torch.float32 else "bf16", te, te, "1x1" if ks == 1 else "3x3")
+        if _prof_shapes:
+            name += " M=%d N=%d K=%d" % (M, Cout, K)
         _prof_wrap(name, 2.0 * M * Cout * K, go)
     _lib.check(L.mdm_conv_wgrad_reduce(_p(ws), _p(dw), _p(dbias), _p(dy), M, Cin, Cout, ks, 0 if out is None else 1, _dt(x),
                                        _stream()), "mdm_conv_wgrad_reduce")

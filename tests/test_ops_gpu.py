@@ -55,6 +55,12 @@ def nchw(t_nhwc):
         (4, 256, 256, 16, 72, 3, 2),    # same, stride 2 (forward) + transposed gradient
         (3, 24, 20, 264, 328, 3, 1),    # Cout >= 256 and K >= 256: the 256x256 transpose-read wgrad tile, ragged
         (2, 16, 16, 512, 256, 1, 1),    # same, 1x1
+        # Cin % 64 == 0 (bf16): the buffer-addressed k-loop (conv_gemm_bl_kernel), 128x128 and 256x256 tiles
+        (3, 20, 24, 128, 136, 3, 1),    # 128x128, ragged M / N, image borders inside a tile
+        (2, 18, 22, 64, 200, 3, 2),     # 128x128, stride 2
+        (8, 127, 63, 128, 320, 3, 1),   # 256x256 forward (ragged M / N), 128x128 input gradient
+        (8, 127, 63, 128, 264, 1, 1),   # 256x256, 1x1
+        (8, 254, 126, 64, 264, 3, 2),   # 256x256, stride 2
     ],
 )
 def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
