@@ -75,66 +75,79 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
   // bias / activation / residual are applied in registers (fp32); the finished tile is then staged through
   // LDS (free after the k-loop) so that HBM sees whole 16-byte chunks of complete output rows instead of the
   // 8-byte-per-lane fragments of the MFMA layout (the output-heavy 1x1 convs -- qkv, FFN up -- were store-bound).
+  if (p.dbg & 8) return;
   T* __restrict__ Y = reinterpret_cast<T*>(p.y);
   T* __restrict__ Ypre = reinterpret_cast<T*>(p.ypre);
   const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
   const T* __restrict__ AUX = reinterpret_cast<const T*>(p.aux);
-  constexpr int PITCH = (sizeof(T) == 2 && BM * (BN * 2 + 16) <= LDS_BYTES) ? BN * 2 + 16 : BN * (int)sizeof(T);   // bytes per staged row
+  // Staged rows are unpadded; the 16-byte chunk index is XOR-swizzled with the row instead, so the 16 rows a lane
+  // group writes (row stride = a multiple of 256 B = the whole bank array) land on 16 different chunks.  (Unswizzled,
+  // the 256x256 tile -- too large to pad -- wrote with 16-way bank conflicts and stored at 2 TB/s instead of 6-7.)
+  constexpr int PITCH = BN * (int)sizeof(T);
+  constexpr int SWZ = (BN / EPV >= 32 ? 32 : BN / EPV) - 1;
   static_assert(BM * PITCH <= LDS_BYTES, "output tile must fit the k-loop LDS");
   constexpr int OCH = BN / EPV;                                    // 16-byte chunks per staged row
   if ((p.Cout % EPV) == 0) {
-    const int first_pass = (p.act == 1 && Ypre) ? 0 : 1;
-    for (int pass = first_pass; pass < 2; ++pass) {
+    // 1. accumulators + bias -> T -> LDS, branch-free (rows / columns past the edge carry garbage that is never stored)
+    f32x4 bv[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int ml = wm * TM + i * 16 + l16, m = m0 + ml;
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * TN + j * 16 + quad * 4;
+      bv[j] = (p.bias && n < p.Cout) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int nl = wn * TN + j * 16 + quad * 4, n = n0 + nl;
-          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          const bool live = m < p.M && n < p.Cout;   // Cout % 4 == 0 here: all four or none
-          if (live) {
-            const size_t o = (size_t)m * p.Cout + n;
-            if (p.bias) {
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    for (int i = 0; i < MT; ++i) {
+      const int ml = wm * TM + i * 16 + l16;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += bv[e];
-            }
-            if (pass == 1) {
-              if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-              } else if (p.act == 2) {
-                float a4[4];
-                load4(AUX + o, a4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(a4[e]);
-              }
-              if (R) {
-                float r4[4];
-                load4(R + o, r4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += r4[e];
-              }
-            }
-          }
-          char* dst = smem + ml * PITCH + nl * (int)sizeof(T);
-          if constexpr (sizeof(T) == 4) {
-            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-          } else {
-            *reinterpret_cast<bf16x4*>(dst) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          }
+      for (int j = 0; j < NT; ++j) {
+        const int nl = wn * TN + j * 16 + quad * 4;
+        const f32x4 v = acc[i][j] + bv[j];
+        constexpr int CPL = 16 / (4 * (int)sizeof(T));   // lanes' 4-element groups per 16-byte chunk (2 bf16 / 1 fp32)
+        const int cl = nl / EPV;
+        char* dst = smem + ml * PITCH + ((cl ^ (ml & SWZ)) << 4) + ((nl / 4) % CPL) * 8;
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          *reinterpret_cast<bf16x4*>(dst) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
         }
       }
-      __syncthreads();
-      T* __restrict__ OUT = pass == 0 ? Ypre : Y;
-      for (int idx = tid; idx < BM * OCH; idx += NT_) {
-        const int row = idx / OCH, ch = idx - row * OCH;
-        const int m = m0 + row, n = n0 + ch * EPV;
-        if (m < p.M && n < p.Cout)
-          *reinterpret_cast<uint4*>(OUT + (size_t)m * p.Cout + n) = *reinterpret_cast<const uint4*>(smem + row * PITCH + ch * 16);
+    }
+    __syncthreads();
+    // 2. whole 16-byte chunks of complete rows: (store the pre-activation) -> activation -> (+ residual) -> store.
+    //    The activation sees the value already rounded to T -- what the reference's autocast graph does too
+    //    (conv output in bf16, then GELU / add as separate bf16 ops); in fp32 mode nothing is rounded.
+    const int act = p.act;
+    const bool skip_store = (p.dbg & 4) != 0;
+#pragma unroll 4
+    for (int idx = tid; idx < BM * OCH; idx += NT_) {
+      const int row = idx / OCH, ch = idx - row * OCH;
+      const int m = m0 + row, n = n0 + ch * EPV;
+      if (m >= p.M || n >= p.Cout || skip_store) continue;
+      const size_t o = (size_t)m * p.Cout + n;
+      const uint4 raw = *reinterpret_cast<const uint4*>(smem + row * PITCH + ((ch ^ (row & SWZ)) << 4));
+      if (act == 0 && !R) {
+        *reinterpret_cast<uint4*>(Y + o) = raw;
+        continue;
       }
-      if (pass == 0) __syncthreads();
+      Chunk<T> c;
+      c.load(reinterpret_cast<const T*>(&raw));
+      if (act == 1) {
+        if (Ypre) *reinterpret_cast<uint4*>(Ypre + o) = raw;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) c.v[e] = gelu_f(c.v[e]);
+      } else if (act == 2) {
+        Chunk<T> ax;
+        ax.load(AUX + o);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) c.v[e] *= dgelu_f(ax.v[e]);
+      }
+      if (R) {
+        Chunk<T> rr;
+        rr.load(R + o);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) c.v[e] += rr.v[e];
+      }
+      c.store(Y + o);
     }
     return;
   }
@@ -878,7 +891,7 @@ __device__ __forceinline__ void load_frags_tr_big(Frag<bf16> (&af)[8], Frag<bf16
 // BIG = 0: 128 x 128 tile, 4 waves (wave tile 64 x 64), 256-byte rows, 2 blocks / CU
 // BIG = 1: 256 x 256 tile, 8 waves (wave tile 128 x 64), 512-byte rows, 1 block / CU
 template <int MODE, int BIG>
-__global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArgs p) {
+__global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_tr_kernel(WgradArgs p) {
   typedef bf16 T;
   constexpr int EPV = 8, BKM = 64;
   constexpr int NTHR = BIG ? 512 : 256;
@@ -1092,6 +1105,272 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void conv_wgrad_tr_kernel(WgradArg
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// bf16 wgrad main path: the tile / LDS image / transpose reads of conv_wgrad_tr_kernel with the loader and k-loop
+// of conv_gemm_bl_kernel.
+//   * Loader: both operands are rows of a pixel-major matrix whose row index advances by 64 per reduction tile, so
+//     a lane's gather offset is fixed for the whole loop (row-in-tile, channel chunk, tap shift) and the tile is a
+//     wave-uniform SGPR offset.  Per tile the only vector work is the halo / tail test of the 4 rows a lane stages
+//     (H, W powers of two: shifts and masks); rows that fail use an offset past num_records (reads zeros).
+//   * k-loop: phase A = MFMAs of k-step 0 with the k-step-1 fragments re-loaded row by row behind them, barrier
+//     (LDS reads of the tile drained, next tile landed), phase B = MFMAs of k-step 1 with the DMA of tile + 2 and
+//     the k-step-0 fragments of tile + 1 behind them.  Transpose reads stay inline asm (the builtin makes hipcc
+//     drain vmcnt before every read); their completion is counted by hand: lgkmcnt(N) ahead of phase-A rows (N
+//     = LDS ops issued after that row's reads, capped at 15), lgkmcnt(0) at the barrier.
+// Host-checked requirements (else conv_wgrad_tr_kernel): 1x1, or 3x3 stride 1 with H, W powers of two; operands
+// below 0x7F000000 bytes.
+// ---------------------------------------------------------------------------
+#define MDM_TR2(lo, hi, addr, OFF)                                                                          \
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                \
+               : "=&v"(lo), "=&v"(hi)                                                                       \
+               : "v"(addr), "n"(OFF), "n"((OFF) + 4 * ROWB)                                                 \
+               : "memory")
+
+// the two 64-bit halves of a transpose-read fragment stay dword vectors until they are concatenated (16-bit element
+// shuffles would make hipcc touch the registers while the read is still in flight)
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ Frag<bf16> frag_of(const u32x2& lo, const u32x2& hi) {
+  const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  Frag<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, v);
+  return f;
+}
+
+// acc + sum of the 8 bf16 values of a fragment
+__device__ __forceinline__ float frag_sum(const Frag<bf16>& f, float acc) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const bf16x2 one = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{f.v[2 * q], f.v[2 * q + 1]}, one, acc, false);
+  return acc;
+}
+
+template <int MODE, int BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(WgradArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef bf16 T;
+  constexpr int EPV = 8, BKM = 64;
+  constexpr int NTHR = BIG ? 512 : 256;
+  constexpr int BM = BIG ? 256 : 128, BN = BM;
+  constexpr int TM = BIG ? 128 : 64, TN = 64, MT = TM / 16, NT = 4;
+  constexpr int ROWB = BM * 2;
+  constexpr int CPRW = ROWB / 16;
+  constexpr int RPP = NTHR / CPRW;                             // 16 rows per staging pass
+  constexpr int A_BYTES = BKM * ROWB, STAGE = 2 * A_BYTES;
+  constexpr int NWN = BIG ? 4 : 2;
+  constexpr int KS1 = 32 * ROWB;                               // byte offset of k-step 1 inside a tile
+  constexpr unsigned INVALID = 0x7F000000u;
+  constexpr int WAITN = 2 * (MT + NT - 1) > 15 ? 15 : 2 * (MT + NT - 1);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int quad = lane >> 4, l16 = lane & 15;
+
+  const int tiles_k = (p.K + BN - 1) / BN;
+  const int tiles_n = (p.Cout + BM - 1) / BM;
+  const int tiles = tiles_k * tiles_n;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lid / tiles;
+  const int t = lid - split * tiles;
+  const int n0 = (t / tiles_k) * BM, k0 = (t % tiles_k) * BN;
+
+  // ---- loader role (see conv_wgrad_tr_kernel): physical slot ps of rows srow + 16 j --------------------------
+  const int ps = tid % CPRW;
+  const int srow = tid / CPRW;
+  const int lc = ((((ps >> 1) ^ tr_swz(srow)) << 1) | (ps & 1));
+  const int a_col = n0 + lc * EPV;
+  const int kk = k0 + lc * EPV;
+  int tap = 0, cin = kk;
+  if (MODE != MODE_1x1) { tap = kk / p.Cin; cin = kk - tap * p.Cin; }
+  const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
+  const unsigned bias = MODE == MODE_3x3 ? (unsigned)(p.W + 1) * p.Cin * 2u : 0u;
+  unsigned a_vo[4], b_vo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned r = j * RPP + srow;
+    a_vo[j] = a_col < p.Cout ? (r * p.Cout + a_col) * 2u : INVALID;
+    b_vo[j] = kk < p.K ? (r * p.Cin + cin) * 2u + (MODE == MODE_3x3 ? (unsigned)(kh * p.W + kw) * p.Cin * 2u : 0u) : INVALID;
+  }
+  const unsigned a_bytes = (unsigned)p.M * p.Cout * 2u;
+  const unsigned b_bytes = (unsigned)p.N * p.H * p.W * p.Cin * 2u + bias;
+  char* const a_base = const_cast<char*>(reinterpret_cast<const char*>(p.dy));
+  char* const b_base = const_cast<char*>(reinterpret_cast<const char*>(p.x)) - bias;
+  const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
+  const int logW = 31 - __builtin_clz(p.W);
+
+  const int mt_begin = split * p.mtiles_per_split;
+  const int mt_total = (p.M + BKM - 1) / BKM;
+  const int mt_end = min(mt_total, mt_begin + p.mtiles_per_split);
+  const int nt = mt_end - mt_begin;
+
+#define MDM_BLDS(rs, lds_off, voff, soff)                                                                   \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds_off), 16, voff, soff, 0, 0)
+  // wave-uniform state of reduction tile `it_` of this split (empty descriptors past the last one)
+#define MDM_WG_TILE_STATE(it_)                                                                              \
+  const bool more_ = (it_) < nt;                                                                            \
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(a_base, 0, more_ ? a_bytes : 0u, 0x00020000);         \
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(b_base, 0, more_ ? b_bytes : 0u, 0x00020000);         \
+  const int mb_ = (mt_begin + (it_)) * BKM;                                                                 \
+  const int a_soff = mb_ * p.Cout * 2, b_soff = mb_ * p.Cin * 2;
+  // piece q (0..7) of a tile: row pass q >> 1, operand q & 1 (dY, then X)
+#define MDM_WG_PIECE(stage, q)                                                                              \
+  {                                                                                                         \
+    constexpr int j_ = (q) >> 1;                                                                            \
+    const int m_ = mb_ + j_ * RPP + srow;                                                                   \
+    bool v_ = m_ < p.M;                                                                                     \
+    if (((q) & 1) == 0) {                                                                                   \
+      MDM_BLDS(rsA, (stage) + j_ * (RPP * ROWB) + wave_lds, v_ ? a_vo[j_] : INVALID, a_soff);               \
+    } else {                                                                                                \
+      if (MODE == MODE_3x3) {                                                                               \
+        const int ow_ = m_ & (p.W - 1), oh_ = (m_ >> logW) & (p.H - 1);                                     \
+        v_ = v_ && (unsigned)(oh_ + kh - 1) < (unsigned)p.H && (unsigned)(ow_ + kw - 1) < (unsigned)p.W;    \
+      }                                                                                                     \
+      MDM_BLDS(rsB, (stage) + A_BYTES + j_ * (RPP * ROWB) + wave_lds, v_ ? b_vo[j_] : INVALID, b_soff);     \
+    }                                                                                                       \
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.bslab != nullptr && k0 == 0 && wn == 0;
+  // bias gradient = column sums of dY: the waves that own k-tile 0 add up the dY^T fragments they already hold
+  // (8 pixels of one channel per lane) with v_dot2c_f32_bf16 against (1, 1) -- one fp32 register per fragment row
+  float bsum[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) bsum[i] = 0.f;
+
+  unsigned fa[MT], fb[NT];
+  {
+    const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int r0 = quad * 8 + (l16 >> 2);
+    const int fsw = (l16 >> 2) | ((quad & 1) << 2);
+#pragma unroll
+    for (int c = 0; c < MT; ++c) fa[c] = smem_base + r0 * ROWB + (((wm * MT + c) ^ fsw) << 5) + ((l16 & 3) << 3);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) fb[c] = smem_base + A_BYTES + r0 * ROWB + (((wn * NT + c) ^ fsw) << 5) + ((l16 & 3) << 3);
+  }
+
+  if (nt > 0) {
+    {
+      MDM_WG_TILE_STATE(0);
+      MDM_WG_PIECE(smem, 0); MDM_WG_PIECE(smem, 1); MDM_WG_PIECE(smem, 2); MDM_WG_PIECE(smem, 3);
+      MDM_WG_PIECE(smem, 4); MDM_WG_PIECE(smem, 5); MDM_WG_PIECE(smem, 6); MDM_WG_PIECE(smem, 7);
+    }
+    {
+      MDM_WG_TILE_STATE(1);
+      MDM_WG_PIECE(smem + STAGE, 0); MDM_WG_PIECE(smem + STAGE, 1); MDM_WG_PIECE(smem + STAGE, 2); MDM_WG_PIECE(smem + STAGE, 3);
+      MDM_WG_PIECE(smem + STAGE, 4); MDM_WG_PIECE(smem + STAGE, 5); MDM_WG_PIECE(smem + STAGE, 6); MDM_WG_PIECE(smem + STAGE, 7);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // raw transpose-read results in flight: [fragment][pixels 0-3 / 4-7]
+    u32x2 ra[MT][2], rb0[NT][2], rb1[NT][2];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) MDM_TR2(rb0[c][0], rb0[c][1], fb[c], 0);
+#pragma unroll
+    for (int c = 0; c < MT; ++c) MDM_TR2(ra[c][0], ra[c][1], fa[c], 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // one reduction tile; BIAS = this wave also accumulates the column sums of dY (ones x dY^T fragment)
+#define MDM_WG_ITER(BIAS)                                                                                   \
+    {                                                                                                       \
+      const unsigned so = (unsigned)((it & 1) * STAGE), sn = (unsigned)(((it + 1) & 1) * STAGE);            \
+      /* ---- phase A: k-step 0 of tile it */                                                               \
+      _Pragma("unroll") for (int c = 0; c < NT; ++c) { const unsigned ad = fb[c] + so; MDM_TR2(rb1[c][0], rb1[c][1], ad, KS1); } \
+      Frag<T> bq[NT];                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                      \
+        if (i == 0) {                                                                                       \
+          asm volatile("s_waitcnt lgkmcnt(%8)"                                                              \
+                       : "+v"(rb0[0][0]), "+v"(rb0[0][1]), "+v"(rb0[1][0]), "+v"(rb0[1][1]), "+v"(rb0[2][0]), \
+                         "+v"(rb0[2][1]), "+v"(rb0[3][0]), "+v"(rb0[3][1])                                  \
+                       : "n"(WAITN) : "memory");                                                            \
+          _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[j] = frag_of(rb0[j][0], rb0[j][1]);             \
+        }                                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ra[i][0]), "+v"(ra[i][1]) : "n"(WAITN) : "memory");     \
+        const Frag<T> aq = frag_of(ra[i][0], ra[i][1]);                                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) mma16(acc[i][j], bq[j], aq);                         \
+        if (BIAS) bsum[i] = frag_sum(aq, bsum[i]);                                                          \
+        { const unsigned ad = fa[i] + so; MDM_TR2(ra[i][0], ra[i][1], ad, KS1); }                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+      }                                                                                                     \
+      /* every LDS read of tile it has returned; tile it + 1 has landed */                                  \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
+      __builtin_amdgcn_s_barrier();                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      /* ---- phase B: k-step 1 of tile it; DMA of tile it + 2; k-step-0 fragments of tile it + 1 */        \
+      MDM_WG_TILE_STATE(it + 2);                                                                            \
+      char* const dst = smem + so;                                                                          \
+      _Pragma("unroll") for (int c = 0; c < NT; ++c) { const unsigned ad = fb[c] + sn; MDM_TR2(rb0[c][0], rb0[c][1], ad, 0); } \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[j] = frag_of(rb1[j][0], rb1[j][1]);                 \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                      \
+        const Frag<T> aq = frag_of(ra[i][0], ra[i][1]);                                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) mma16(acc[i][j], bq[j], aq);                         \
+        if (BIAS) bsum[i] = frag_sum(aq, bsum[i]);                                                          \
+        if (MT == 8) { MDM_WG_PIECE_RT(dst, i) } else { MDM_WG_PIECE_RT(dst, 2 * i) MDM_WG_PIECE_RT(dst, 2 * i + 1) } \
+        { const unsigned ad = fa[i] + sn; MDM_TR2(ra[i][0], ra[i][1], ad, 0); }                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+      }                                                                                                     \
+    }
+    // piece index known only after unrolling: dispatch to the literal forms
+#define MDM_WG_PIECE_RT(stage, q)                                                                           \
+    switch (q) {                                                                                            \
+      case 0: MDM_WG_PIECE(stage, 0) break; case 1: MDM_WG_PIECE(stage, 1) break;                           \
+      case 2: MDM_WG_PIECE(stage, 2) break; case 3: MDM_WG_PIECE(stage, 3) break;                           \
+      case 4: MDM_WG_PIECE(stage, 4) break; case 5: MDM_WG_PIECE(stage, 5) break;                           \
+      case 6: MDM_WG_PIECE(stage, 6) break; default: MDM_WG_PIECE(stage, 7) break;                          \
+    }
+    // the two loop bodies execute the same number of barriers, so the waves of a block may take different ones
+    if (do_bias) {
+      for (int it = 0; it < nt; ++it) MDM_WG_ITER(true)
+    } else {
+      for (int it = 0; it < nt; ++it) MDM_WG_ITER(false)
+    }
+    // the fragments pre-read for the tile after the last are never used; retire them before the registers die
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef MDM_WG_PIECE_RT
+#undef MDM_WG_ITER
+  }
+#undef MDM_WG_PIECE
+#undef MDM_WG_TILE_STATE
+#undef MDM_BLDS
+
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float v = bsum[i];                       // lanes l16, l16 + 16, + 32, + 48 hold the four pixel groups of a k-step
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + wm * TM + i * 16 + l16;
+      if (quad == 0 && n < p.Cout) p.bslab[(size_t)split * p.Cout + n] = v;
+    }
+  }
+  float* __restrict__ S = p.slab + (size_t)split * p.Cout * p.K;
+  const bool vec_ok = (p.K & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int n = n0 + wm * TM + i * 16 + l16;
+    if (n >= p.Cout) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int k = k0 + wn * TN + j * 16 + quad * 4;
+      if (k >= p.K) continue;
+      float* o = S + (size_t)n * p.K + k;
+      if (vec_ok) {
+        *reinterpret_cast<f32x4*>(o) = acc[i][j];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k + e < p.K) o[e] = acc[i][j][e];
+      }
+    }
+  }
+#endif
+}
+#undef MDM_TR2
 
 // dW_oihw[o][i][t] = sum_s slab[s][o][t*Cin + i]      (taps = 1 or 9)
 // One block per (o, 64-channel block): the 9 x 64 slab values are read as 9 contiguous runs, transposed through
@@ -1352,7 +1631,7 @@ static int g_bl = -1;   // MDM_HIP_BLGEMM=0 falls back to the flat-address loade
 template <typename T, int MODE>
 static bool conv_bl_ok(const ConvArgs& a) {
   if (g_bl < 0) { const char* e = getenv("MDM_HIP_BLGEMM"); g_bl = e ? atoi(e) : 1; }
-  if (!g_bl || sizeof(T) != 2 || MODE == MODE_3x3_T2 || a.dbg) return false;
+  if (!g_bl || sizeof(T) != 2 || MODE == MODE_3x3_T2 || (a.dbg & 3)) return false;
   if (a.K % 64 != 0 || (MODE == MODE_3x3 && a.kblk == 0)) return false;
   const size_t lim = 0x7F000000u;
   const size_t bias = MODE == MODE_3x3 ? (size_t)(a.W + 1) * a.Cin * 2 : 0;
@@ -1468,6 +1747,19 @@ static void wgrad_set_smem(K kern, int bytes) {
 
 extern "C" int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulate, int dtype, void* stream);
 
+// buffer-addressed wgrad (conv_wgrad_bl_kernel) usable for this bf16 problem?
+static bool wgrad_bl_ok(const WgradArgs& a, int ksize) {
+  if (g_bl < 0) { const char* e = getenv("MDM_HIP_BLGEMM"); g_bl = e ? atoi(e) : 1; }
+  if (!g_bl) return false;
+  if (ksize == 3) {
+    if (a.stride != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+    if ((a.H & (a.H - 1)) || (a.W & (a.W - 1))) return false;
+  }
+  const size_t lim = 0x7F000000u;
+  const size_t bias = ksize == 3 ? (size_t)(a.W + 1) * a.Cin * 2 : 0;
+  return (size_t)a.M * a.Cout * 2 <= lim && (size_t)a.N * a.H * a.W * a.Cin * 2 + bias <= lim;
+}
+
 extern "C" int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, float* ws, int N, int H, int W, int Cin,
                               int Ho, int Wo, int Cout, int ksize, int stride, int dtype, void* stream) {
   MDM_CHECK_ARG(x && dy && ws);
@@ -1499,12 +1791,24 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, floa
     wgrad_set_smem(conv_wgrad_tr_kernel<MODE_3x3, 0>, smem);
     wgrad_set_smem(conv_wgrad_tr_kernel<MODE_1x1, 1>, smem_big);
     wgrad_set_smem(conv_wgrad_tr_kernel<MODE_3x3, 1>, smem_big);
+    wgrad_set_smem(conv_wgrad_bl_kernel<MODE_1x1, 0>, smem);
+    wgrad_set_smem(conv_wgrad_bl_kernel<MODE_3x3, 0>, smem);
+    wgrad_set_smem(conv_wgrad_bl_kernel<MODE_1x1, 1>, smem_big);
+    wgrad_set_smem(conv_wgrad_bl_kernel<MODE_3x3, 1>, smem_big);
     attr_done = true;
   }
   dim3 grid(tiles * a.splits);
   if (dtype == DT_F32) {
     if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_kernel<float, MODE_1x1>), grid, dim3(256), smem, st, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<float, MODE_3x3>), grid, dim3(256), smem, st, a);
+  } else if (wgrad_bl_ok(a, ksize)) {
+    if (te == 256) {
+      if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_1x1, 1>), grid, dim3(512), smem_big, st, a);
+      else hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_3x3, 1>), grid, dim3(512), smem_big, st, a);
+    } else {
+      if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_1x1, 0>), grid, dim3(256), smem, st, a);
+      else hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_3x3, 0>), grid, dim3(256), smem, st, a);
+    }
   } else if (te == 256) {
     if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_1x1, 1>), grid, dim3(512), smem_big, st, a);
     else hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_3x3, 1>), grid, dim3(512), smem_big, st, a);

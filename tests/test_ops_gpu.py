@@ -61,6 +61,11 @@ def nchw(t_nhwc):
         (8, 127, 63, 128, 320, 3, 1),   # 256x256 forward (ragged M / N), 128x128 input gradient
         (8, 127, 63, 128, 264, 1, 1),   # 256x256, 1x1
         (8, 254, 126, 64, 264, 3, 2),   # 256x256, stride 2
+        # power-of-two images / 1x1: the buffer-addressed wgrad (conv_wgrad_bl_kernel)
+        (3, 4, 8, 64, 72, 3, 1),        # 128x128 tile, ragged reduction tail (M = 96), image borders everywhere
+        (5, 9, 7, 64, 136, 1, 1),       # 128x128, 1x1, M = 315
+        (2, 16, 16, 256, 320, 3, 1),    # 256x256 tile (K = 2304), ragged Cout
+        (4, 128, 128, 64, 264, 1, 1),   # 256x256, 1x1 (M = 65536), K below one tile
     ],
 )
 def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
