@@ -14,6 +14,8 @@
 //   y = act(a[n,c] * x + b[n,c]),  a = gamma*f*rstd, b = (beta - mean*rstd*gamma)*f + tb, f = 1 + ta
 // Backward = gn_bwd_partial (reads dy, x) -> gn_bwd_finalize -> gn_bwd_apply (reads dy, x, writes dx)
 //   dz = dy * act'(a*x + b);  dx = a*dz + q[n,g]*x + r[n,g]
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mdm {
@@ -245,14 +247,26 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
 }
 
 // dgamma[c] = sum_n pgrad[n][c][0]; dbeta[c] = sum_n pgrad[n][c][1]
-__global__ void gn_bwd_param_kernel(const float* __restrict__ pgrad, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, int N, int C, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 32 channels x 8 interleaved sample ranges (256 threads), fixed-order LDS reduction
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ pgrad, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int N, int C, int accumulate) {
+  __shared__ float red[8][32][2];
+  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float a = 0.f, b = 0.f;
-  for (int n = 0; n < N; ++n) { a += pgrad[((size_t)n * C + c) * 2]; b += pgrad[((size_t)n * C + c) * 2 + 1]; }
-  dgamma[c] = accumulate ? dgamma[c] + a : a;
-  dbeta[c] = accumulate ? dbeta[c] + b : b;
+  if (c < C)
+    for (int n = part; n < N; n += 8) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(pgrad + ((size_t)n * C + c) * 2);
+      a += v[0]; b += v[1];
+    }
+  red[part][cl][0] = a; red[part][cl][1] = b;
+  __syncthreads();
+  if (part == 0 && c < C) {
+#pragma unroll
+    for (int q = 1; q < 8; ++q) { a += red[q][cl][0]; b += red[q][cl][1]; }
+    dgamma[c] = accumulate ? dgamma[c] + a : a;
+    dbeta[c] = accumulate ? dbeta[c] + b : b;
+  }
 }
 
 // ---- backward stage 3: dx = a*dz + q*x + r ------------------------------------------
@@ -286,6 +300,254 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
     cd.store(dx + i * EPV);
   }
+}
+
+// ---------------------------------------------------------------------------------
+// Single-kernel GroupNorm for small images (the 16x16 / 32x32 levels: 80 of the 97 GroupNorms of the 64x64 U-Net).
+// One 1024-thread block owns (sample n, a slice of whole groups, <= 64 channels): thread (r, c) = (tid / LPR,
+// tid % LPR) keeps the 16-byte chunks (pixel r + it * R, chunk c) of the slice in registers, so x (and dy) are read
+// from HBM exactly once, the statistics are the exact two-pass ones, and the three-kernel sequence
+// partial -> finalize -> apply (each ~15 us of launch / tail latency on a 25 MB tensor) becomes one launch.
+// LPR = chunk lanes per pixel row (8 for bf16, 16 for fp32; lanes past the slice idle), R = 1024 / LPR rows per pass,
+// NI = passes (host guarantees HW <= NI * R).  Reductions: shuffles across the rows of a wave, then LDS across waves
+// in a fixed order -> deterministic.
+// ---------------------------------------------------------------------------------
+template <typename T> struct GnF;
+template <> struct GnF<bf16> { static constexpr int LPR = 8; };
+template <> struct GnF<float> { static constexpr int LPR = 16; };
+
+template <int LPR>
+__device__ __forceinline__ float rows_sum(float v) {   // sum over the lanes of a wave that share tid % LPR
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int ACT, int NI>
+__global__ __launch_bounds__(1024) void gn_fused_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const T* __restrict__ film,
+                                                            T* __restrict__ y, float* __restrict__ stats,
+                                                            float* __restrict__ coef, int HW, int C, int G, int CB,
+                                                            float eps) {
+  constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = 1024 / LPR, NW = 16;
+  __shared__ float sh[NW][LPR];
+  __shared__ float gmean[8], grstd[8];
+  const int n = blockIdx.x, cb0 = blockIdx.y * CB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = tid % LPR, r = tid / LPR;
+  const int cpg = C / G, cpc = cpg / EPV, gpb = CB / cpg;
+  const bool active = c * EPV < CB;
+  const int ch0 = cb0 + c * EPV;
+  const int gl = active ? (c * EPV) / cpg : 0;
+  const T* xn = x + (size_t)n * HW * C + ch0;
+  uint4 raw[NI];   // the slice stays in registers in storage format (converted on use: 4 registers per chunk)
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int p = r + it * R;
+    raw[it] = uint4{0u, 0u, 0u, 0u};
+    if (active && p < HW) {
+      raw[it] = *reinterpret_cast<const uint4*>(xn + (size_t)p * C);
+      Chunk<T> v;
+      v.load(reinterpret_cast<const T*>(&raw[it]));
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) s += v.v[e];
+    }
+  }
+  const float cnt = (float)cpg * (float)HW;
+  s = rows_sum<LPR>(s);
+  if (lane < LPR) sh[wave][lane] = s;
+  __syncthreads();
+  if (tid < gpb) {
+    float t = 0.f;
+    for (int w = 0; w < NW; ++w)
+      for (int cc = tid * cpc; cc < (tid + 1) * cpc; ++cc) t += sh[w][cc];
+    gmean[tid] = t / cnt;
+  }
+  __syncthreads();
+  const float mu = gmean[gl];
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int p = r + it * R;
+    if (active && p < HW) {
+      Chunk<T> v;
+      v.load(reinterpret_cast<const T*>(&raw[it]));
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { const float d = v.v[e] - mu; q += d * d; }
+    }
+  }
+  q = rows_sum<LPR>(q);
+  if (lane < LPR) sh[wave][lane] = q;
+  __syncthreads();
+  if (tid < gpb) {
+    float t = 0.f;
+    for (int w = 0; w < NW; ++w)
+      for (int cc = tid * cpc; cc < (tid + 1) * cpc; ++cc) t += sh[w][cc];
+    const float rstd = rsqrtf(t / cnt + eps);
+    grstd[tid] = rstd;
+    const int g = cb0 / cpg + tid;
+    stats[((size_t)n * G + g) * 2] = gmean[tid];
+    stats[((size_t)n * G + g) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  if (!active) return;
+  const float rstd = grstd[gl];
+  float a[EPV], b[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    const int ch = ch0 + e;
+    float f = 1.f, tb = 0.f;
+    if (film) { f = 1.f + to_f32(film[(size_t)n * 2 * C + ch]); tb = to_f32(film[(size_t)n * 2 * C + C + ch]); }
+    const float ga = gamma[ch], be = beta[ch];
+    a[e] = ga * f * rstd;
+    b[e] = (be - mu * rstd * ga) * f + tb;
+  }
+  if (r == 0) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      coef[((size_t)n * C + ch0 + e) * 2] = a[e];
+      coef[((size_t)n * C + ch0 + e) * 2 + 1] = b[e];
+    }
+  }
+  T* yn = y + (size_t)n * HW * C + ch0;
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int p = r + it * R;
+    if (p < HW) {
+      Chunk<T> v;
+      v.load(reinterpret_cast<const T*>(&raw[it]));
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const float z = a[e] * v.v[e] + b[e];
+        v.v[e] = ACT ? silu_f(z) : z;
+      }
+      v.store(yn + (size_t)p * C);
+    }
+  }
+}
+
+template <typename T, int ACT, int NI>
+__global__ __launch_bounds__(1024) void gn_fused_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const T* __restrict__ film, const float* __restrict__ stats,
+                                                            const float* __restrict__ coef, T* __restrict__ dx,
+                                                            T* __restrict__ dfilm, float* __restrict__ pgrad, int HW,
+                                                            int C, int G, int CB) {
+  constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = 1024 / LPR, NW = 16;
+  __shared__ float sh[NW][LPR][2 * EPV];
+  __shared__ float tot[LPR][2 * EPV];
+  __shared__ float sg[LPR][2];
+  const int n = blockIdx.x, cb0 = blockIdx.y * CB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = tid % LPR, r = tid / LPR;
+  const int cpg = C / G, cpc = cpg / EPV;
+  const bool active = c * EPV < CB;
+  const int ch0 = active ? cb0 + c * EPV : cb0;
+  const int gl = active ? (c * EPV) / cpg : 0;
+  const size_t base = (size_t)n * HW * C + ch0;
+  float a[EPV], b[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    a[e] = coef[((size_t)n * C + ch0 + e) * 2];
+    b[e] = coef[((size_t)n * C + ch0 + e) * 2 + 1];
+  }
+  uint4 rx[NI], rd[NI];   // x and dy of the slice, storage format
+  float A1[EPV], A2[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) { A1[e] = 0.f; A2[e] = 0.f; }
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int p = r + it * R;
+    rx[it] = uint4{0u, 0u, 0u, 0u}; rd[it] = uint4{0u, 0u, 0u, 0u};
+    if (active && p < HW) {
+      rx[it] = *reinterpret_cast<const uint4*>(x + base + (size_t)p * C);
+      rd[it] = *reinterpret_cast<const uint4*>(dy + base + (size_t)p * C);
+      Chunk<T> vx, vd;
+      vx.load(reinterpret_cast<const T*>(&rx[it]));
+      vd.load(reinterpret_cast<const T*>(&rd[it]));
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        float dz = vd.v[e];
+        if (ACT) dz *= dsilu_f(a[e] * vx.v[e] + b[e]);
+        A1[e] += dz; A2[e] += dz * vx.v[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) { A1[e] = rows_sum<LPR>(A1[e]); A2[e] = rows_sum<LPR>(A2[e]); }
+  if (lane < LPR) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { sh[wave][lane][e] = A1[e]; sh[wave][lane][EPV + e] = A2[e]; }
+  }
+  __syncthreads();
+  if (tid < LPR * 2 * EPV) {
+    const int cc = tid / (2 * EPV), e2 = tid % (2 * EPV);
+    float t = 0.f;
+    for (int w = 0; w < NW; ++w) t += sh[w][cc][e2];
+    tot[cc][e2] = t;
+  }
+  __syncthreads();
+  const int g = ch0 / cpg;
+  const float mu = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
+  float p1 = 0.f, p2 = 0.f;   // this chunk's part of the group sums  sum f*gamma*A1,  sum f*gamma*Xh
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    const int ch = ch0 + e;
+    const float a1 = tot[c][e], a2 = tot[c][EPV + e];
+    const float Xh = rstd * (a2 - mu * a1);
+    float f = 1.f;
+    if (film) f = 1.f + to_f32(film[(size_t)n * 2 * C + ch]);
+    const float ga = gamma[ch], be = beta[ch];
+    if (r == 0 && active) {
+      pgrad[((size_t)n * C + ch) * 2] = f * Xh;
+      pgrad[((size_t)n * C + ch) * 2 + 1] = f * a1;
+      if (film) {
+        dfilm[(size_t)n * 2 * C + ch] = from_f32<T>(ga * Xh + be * a1);
+        dfilm[(size_t)n * 2 * C + C + ch] = from_f32<T>(a1);
+      }
+    }
+    p1 += f * ga * a1;
+    p2 += f * ga * Xh;
+  }
+  if (r == 0) { sg[c][0] = active ? p1 : 0.f; sg[c][1] = active ? p2 : 0.f; }
+  __syncthreads();
+  if (!active) return;
+  float S1 = 0.f, S2 = 0.f;
+  for (int cc = gl * cpc; cc < (gl + 1) * cpc; ++cc) { S1 += sg[cc][0]; S2 += sg[cc][1]; }
+  const float m = (float)cpg * (float)HW;
+  const float qq = -rstd * rstd * S2 / m;
+  const float rr = -rstd * S1 / m - qq * mu;
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int p = r + it * R;
+    if (p < HW) {
+      Chunk<T> vx, vd;
+      vx.load(reinterpret_cast<const T*>(&rx[it]));
+      vd.load(reinterpret_cast<const T*>(&rd[it]));
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        float dz = vd.v[e];
+        if (ACT) dz *= dsilu_f(a[e] * vx.v[e] + b[e]);
+        vd.v[e] = a[e] * dz + qq * vx.v[e] + rr;
+      }
+      vd.store(dx + base + (size_t)p * C);
+    }
+  }
+}
+
+// channels per block of the fused kernels (0 = not applicable -> three-kernel path)
+static int gn_fused_cb(int HW, int C, int G, int dtype, int max_ni) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("MDM_HIP_GN_FUSED"); enabled = e ? atoi(e) : 1; }
+  if (!enabled) return 0;
+  const int epv = dtype == DT_F32 ? 4 : 8, lpr = dtype == DT_F32 ? 16 : 8;
+  const int cpg = C / G;
+  if (cpg % epv != 0 || cpg > lpr * epv) return 0;
+  if (HW > max_ni * (1024 / lpr)) return 0;
+  int gpb = (lpr * epv) / cpg;
+  while (gpb > 1 && (G % gpb != 0 || gpb > 8)) --gpb;
+  return cpg * gpb;
 }
 
 // ---------------------------------------------------------------------------------
@@ -400,6 +662,19 @@ extern "C" int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, 
   const int slabs = gn_slabs(N, HW);
   const int pps = (HW + slabs - 1) / slabs;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (const int cb = gn_fused_cb(HW, C, G, dtype, 8)) {
+    const dim3 grid(N, C / cb);
+    const bool small = HW <= 2 * (1024 / (dtype == DT_F32 ? 16 : 8));   // passes per thread: 2 or 8
+#define MDM_GN_FUSED_FWD(TT, ACT)                                                                                  \
+    if (small) hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, 2>), grid, dim3(1024), 0, st, (const TT*)x, gamma,  \
+                                  beta, (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps);                   \
+    else hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, 8>), grid, dim3(1024), 0, st, (const TT*)x, gamma, beta,  \
+                            (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps)
+    if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_FWD(float, 1); } else { MDM_GN_FUSED_FWD(float, 0); } }
+    else { if (act) { MDM_GN_FUSED_FWD(bf16, 1); } else { MDM_GN_FUSED_FWD(bf16, 0); } }
+#undef MDM_GN_FUSED_FWD
+    MDM_LAUNCH_STATUS();
+  }
   const size_t total_chunks = (size_t)N * HW * C / epv;
   const int ab = (int)((total_chunks + 255) / 256 > 16384 ? 16384 : (total_chunks + 255) / 256);
   if (dtype == DT_F32) {
@@ -430,6 +705,23 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
   float* pgrad = ws + (size_t)N * slabs * C * 2;
   float* qr = pgrad + (size_t)N * C * 2;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // x AND dy stay in registers here: 4 passes at most (beyond that the register file spills; three-kernel path)
+  if (const int cb = gn_fused_cb(HW, C, G, dtype, 4)) {
+    const dim3 grid(N, C / cb);
+    const bool small = HW <= 2 * (1024 / (dtype == DT_F32 ? 16 : 8));
+#define MDM_GN_FUSED_BWD(TT, ACT)                                                                                  \
+    if (small) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 2>), grid, dim3(1024), 0, st, (const TT*)dy,        \
+                                  (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm,     \
+                                  pgrad, HW, C, G, cb);                                                             \
+    else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4>), grid, dim3(1024), 0, st, (const TT*)dy,              \
+                            (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, pgrad,    \
+                            HW, C, G, cb)
+    if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_BWD(float, 1); } else { MDM_GN_FUSED_BWD(float, 0); } }
+    else { if (act) { MDM_GN_FUSED_BWD(bf16, 1); } else { MDM_GN_FUSED_BWD(bf16, 0); } }
+#undef MDM_GN_FUSED_BWD
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pgrad, dgamma, dbeta, N, C, accumulate);
+    MDM_LAUNCH_STATUS();
+  }
   const size_t total_chunks = (size_t)N * HW * C / epv;
   const int ab = (int)((total_chunks + 255) / 256 > 16384 ? 16384 : (total_chunks + 255) / 256);
 #define MDM_GN_BWD(TT, ACT)                                                                                          \
@@ -437,7 +729,7 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
                      (const TT*)x, coef, part, HW, C, slabs, pps);                                                   \
   hipLaunchKernelGGL(gn_bwd_finalize_kernel<TT>, dim3(N), dim3(256), 0, st, part, stats, gamma, beta,                \
                      (const TT*)film, qr, (TT*)dfilm, pgrad, HW, C, G, slabs);                                       \
-  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, pgrad, dgamma, dbeta, N, C,      \
+  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pgrad, dgamma, dbeta, N, C,        \
                      accumulate);                                                                                    \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, ACT>), dim3(ab), dim3(256), 0, st, (const TT*)dy, (const TT*)x, coef, \
                      qr, (TT*)dx, HW, C, G, total_chunks);

@@ -183,6 +183,11 @@ def test_ffn(dtype):
     (2, 256, 768, 32, True, True),
     (2, 49, 1280, 32, False, False),
     (2, 1024, 64, 32, False, True),    # 2 channels / group
+    # whole chunks per group and a small image: the single-kernel (register-resident) GroupNorm
+    (2, 1024, 512, 32, True, True),    # 16 / group, 8 passes forward; backward falls back to three kernels (bf16)
+    (3, 256, 512, 32, False, False),   # no activation
+    (2, 400, 1536, 32, True, True),    # 48 / group (one group per block), 4 passes
+    (2, 256, 256, 32, False, True),    # 8 / group, 8 groups per block
 ])
 def test_group_norm(dtype, N, HW, C, G, film, silu):
     from mdm_hip import ops
