@@ -83,10 +83,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
   // Staged rows are unpadded; the 16-byte chunk index is XOR-swizzled with the row instead, so the 16 rows a lane
   // group writes (row stride = a multiple of 256 B = the whole bank array) land on 16 different chunks.  (Unswizzled,
   // the 256x256 tile -- too large to pad -- wrote with 16-way bank conflicts and stored at 2 TB/s instead of 6-7.)
-  constexpr int PITCH = BN * (int)sizeof(T);
-  constexpr int SWZ = (BN / EPV >= 32 ? 32 : BN / EPV) - 1;
-  static_assert(BM * PITCH <= LDS_BYTES, "output tile must fit the k-loop LDS");
+  // (a row length that is not a power of two -- the 192-wide tile -- is padded by one chunk instead)
   constexpr int OCH = BN / EPV;                                    // 16-byte chunks per staged row
+  constexpr bool POW2 = (OCH & (OCH - 1)) == 0;
+  constexpr int PITCH = BN * (int)sizeof(T) + (POW2 ? 0 : 16);
+  constexpr int SWZ = POW2 ? (OCH >= 32 ? 32 : OCH) - 1 : 0;
+  static_assert(BM * PITCH <= LDS_BYTES, "output tile must fit the k-loop LDS");
   if ((p.Cout % EPV) == 0) {
     // 1. accumulators + bias -> T -> LDS, branch-free (rows / columns past the edge carry garbage that is never stored)
     f32x4 bv[NT];
@@ -1589,28 +1591,6 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
   MDM_LAUNCH_STATUS();
 }
 
-static int g_big_tile = -1;   // MDM_HIP_BIGTILE=0 forces the 128x128 kernel (A/B testing)
-
-// block tile (BM * 1000 + BN) the forward / dgrad kernel uses for a problem
-static int conv_tile_code(int M, int Cout, int dtype) {
-  if (Cout <= 32) return 128032;
-  if (Cout <= 64) return 128064;
-  if (g_big_tile < 0) {
-    const char* e = getenv("MDM_HIP_BIGTILE");
-    g_big_tile = e ? atoi(e) : 2;
-  }
-  const long big_tiles = (long)((M + 255) / 256) * ((Cout + 127) / 128);
-  const long huge_tiles = (long)((M + 255) / 256) * ((Cout + 255) / 256);
-  if (dtype == DT_BF16 && g_big_tile == 2 && huge_tiles >= 256) {
-    const long waves = (huge_tiles + 255) / 256;
-    if (huge_tiles * 5 >= waves * 256 * 4) return 256256;
-  }
-  if (g_big_tile == 1 && big_tiles >= 256) return 256128;
-  return 128128;
-}
-
-extern "C" int mdm_conv_fwd_tile(int M, int Cout, int dtype) { return conv_tile_code(M, Cout, dtype); }
-
 template <int BM, int BN, int WM, int WN, int MODE>
 static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
@@ -1639,33 +1619,57 @@ static bool conv_bl_ok(const ConvArgs& a) {
   return 2 * bias + (size_t)a.K * 2 < 0x00F00000u;   // INVALID + any tile offset stays below 2^31
 }
 
+static int g_big_tile = -1;   // MDM_HIP_BIGTILE=0 forces the 128x128 kernel, MDM_HIP_TILE=<code> any tile (A/B testing)
+static int g_force_tile = -1;
+
+// Block tile (BM * 1000 + BN) of the forward / dgrad kernel for a problem.  bf16: the candidates are 128x128
+// (2 blocks / CU), 256x192 and 256x256 (1 block / CU); the cheapest by rounds x tile area / relative efficiency wins
+// (relative efficiencies measured with tools/kbench.py: the larger tiles move fewer LDS bytes per FLOP; N = 768 --
+// 130 GEMMs of a step -- is exactly one round of 256x192 tiles at M = 16384).
+static int conv_tile_code(int M, int Cout, int dtype) {
+  if (Cout <= 32) return 128032;
+  if (Cout <= 64) return 128064;
+  if (g_big_tile < 0) {
+    const char* e = getenv("MDM_HIP_BIGTILE");
+    g_big_tile = e ? atoi(e) : 2;
+    const char* f = getenv("MDM_HIP_TILE");
+    g_force_tile = f ? atoi(f) : 0;
+  }
+  if (dtype != DT_BF16 || g_big_tile == 0) return 128128;
+  if (g_force_tile) return g_force_tile;
+  if (g_big_tile == 1) return ((long)((M + 255) / 256) * ((Cout + 127) / 128) >= 256) ? 256128 : 128128;
+  const long mt128 = (M + 127) / 128, mt256 = (M + 255) / 256;
+  const long t128 = mt128 * ((Cout + 127) / 128), t192 = mt256 * ((Cout + 191) / 192), t256 = mt256 * ((Cout + 255) / 256);
+  const double c128 = (double)((t128 + 511) / 512) * 2.0 * 1.0 / 0.80;
+  const double c192 = (double)((t192 + 255) / 256) * 3.0 / 0.95;
+  const double c256 = (double)((t256 + 255) / 256) * 4.0 / 1.00;
+  if (c256 <= c192 && c256 <= c128) return 256256;
+  if (c192 <= c128) return 256192;
+  return 128128;
+}
+
+extern "C" int mdm_conv_fwd_tile(int M, int Cout, int dtype) { return conv_tile_code(M, Cout, dtype); }
+
 template <typename T, int MODE>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE, 2>(a, st);
   if (a.Cout <= 64) return launch_conv_cfg<T, 128, 64, 2, 2, MODE, 2>(a, st);
-  if (g_big_tile < 0) {
-    const char* e = getenv("MDM_HIP_BIGTILE");
-    g_big_tile = e ? atoi(e) : 2;
-  }
-  // Tile choice (measured, tools/kbench.py): the 256x256 8-wave tile (wave tile 128x64) halves the LDS bytes per
-  // FLOP of the 128x128 one and wins 10-17 % when it fills the 256 CUs in whole waves; with few or ragged tile
-  // counts the 128x128 kernel (2 blocks / CU) wins.  MDM_HIP_BIGTILE: 0 = always 128x128, 1 = 256x128 3-stage
-  // (counted vmcnt; kept for A/B), 2 = default rule.
-  const long big_tiles = (long)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
-  const long huge_tiles = (long)((a.M + 255) / 256) * ((a.Cout + 255) / 256);
+  const int code = conv_tile_code(a.M, a.Cout, sizeof(T) == 2 ? DT_BF16 : DT_F32);
   if constexpr (sizeof(T) == 2) {
-    if (g_big_tile == 2 && huge_tiles >= 256) {
-      const long waves = (huge_tiles + 255) / 256;
-      if (huge_tiles * 5 >= waves * 256 * 4) {
-        static int pp = -1;
-        if (pp < 0) { const char* e = getenv("MDM_HIP_PINGPONG"); pp = e ? atoi(e) : 0; }   // measured equal to the plain schedule; off by default
-        if constexpr (MODE != MODE_3x3_T2) { if (conv_bl_ok<T, MODE>(a)) return launch_conv_bl<256, 256, 2, 4, MODE>(a, st); }
-        return pp ? launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2, true>(a, st) : launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2, false>(a, st);
-      }
+    bool bl = false;
+    if constexpr (MODE != MODE_3x3_T2) bl = conv_bl_ok<T, MODE>(a);
+    if constexpr (MODE != MODE_3x3_T2) {
+      if (bl && code == 256256) return launch_conv_bl<256, 256, 2, 4, MODE>(a, st);
+      if (bl && code == 256192) return launch_conv_bl<256, 192, 2, 4, MODE>(a, st);
+      if (bl && code == 128128) return launch_conv_bl<128, 128, 2, 2, MODE>(a, st);
+    }
+    if (code == 256256 || (code == 256192 && (long)((a.M + 255) / 256) * ((a.Cout + 255) / 256) >= 200)) {
+      static int pp = -1;
+      if (pp < 0) { const char* e = getenv("MDM_HIP_PINGPONG"); pp = e ? atoi(e) : 0; }   // measured equal to the plain schedule; off by default
+      return pp ? launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2, true>(a, st) : launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2, false>(a, st);
     }
   }
-  if (g_big_tile == 1 && big_tiles >= 256) return launch_conv_cfg<T, 256, 128, 4, 2, MODE, 3>(a, st);
-  if constexpr (sizeof(T) == 2 && MODE != MODE_3x3_T2) { if (conv_bl_ok<T, MODE>(a)) return launch_conv_bl<128, 128, 2, 2, MODE>(a, st); }
+  if (code == 256128) return launch_conv_cfg<T, 256, 128, 4, 2, MODE, 3>(a, st);
   return launch_conv_cfg<T, 128, 128, 2, 2, MODE, 2>(a, st);
 }
 

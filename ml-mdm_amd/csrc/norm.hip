@@ -304,11 +304,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
 
 // ---------------------------------------------------------------------------------
 // Single-kernel GroupNorm for small images (the 16x16 / 32x32 levels: 80 of the 97 GroupNorms of the 64x64 U-Net).
-// One 1024-thread block owns (sample n, a slice of whole groups, <= 64 channels): thread (r, c) = (tid / LPR,
+// One block (256 / 512 / 1024 threads by image size) owns (sample n, a slice of whole groups, <= 64 channels): thread (r, c) = (tid / LPR,
 // tid % LPR) keeps the 16-byte chunks (pixel r + it * R, chunk c) of the slice in registers, so x (and dy) are read
 // from HBM exactly once, the statistics are the exact two-pass ones, and the three-kernel sequence
 // partial -> finalize -> apply (each ~15 us of launch / tail latency on a 25 MB tensor) becomes one launch.
-// LPR = chunk lanes per pixel row (8 for bf16, 16 for fp32; lanes past the slice idle), R = 1024 / LPR rows per pass,
+// LPR = chunk lanes per pixel row (8 for bf16, 16 for fp32; lanes past the slice idle), R = threads / LPR rows per pass,
 // NI = passes (host guarantees HW <= NI * R).  Reductions: shuffles across the rows of a wave, then LDS across waves
 // in a fixed order -> deterministic.
 // ---------------------------------------------------------------------------------
@@ -323,13 +323,13 @@ __device__ __forceinline__ float rows_sum(float v) {   // sum over the lanes of 
   return v;
 }
 
-template <typename T, int ACT, int NI>
-__global__ __launch_bounds__(1024) void gn_fused_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+template <typename T, int ACT, int NI, int NTHR>
+__global__ __launch_bounds__(NTHR) void gn_fused_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const T* __restrict__ film,
                                                             T* __restrict__ y, float* __restrict__ stats,
                                                             float* __restrict__ coef, int HW, int C, int G, int CB,
                                                             float eps) {
-  constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = 1024 / LPR, NW = 16;
+  constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = NTHR / LPR, NW = NTHR / 64;
   __shared__ float sh[NW][LPR];
   __shared__ float gmean[8], grstd[8];
   const int n = blockIdx.x, cb0 = blockIdx.y * CB;
@@ -427,14 +427,14 @@ __global__ __launch_bounds__(1024) void gn_fused_fwd_kernel(const T* __restrict_
   }
 }
 
-template <typename T, int ACT, int NI>
-__global__ __launch_bounds__(1024) void gn_fused_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int ACT, int NI, int NTHR>
+__global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const T* __restrict__ film, const float* __restrict__ stats,
                                                             const float* __restrict__ coef, T* __restrict__ dx,
                                                             T* __restrict__ dfilm, float* __restrict__ pgrad, int HW,
                                                             int C, int G, int CB) {
-  constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = 1024 / LPR, NW = 16;
+  constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = NTHR / LPR, NW = NTHR / 64;
   __shared__ float sh[NW][LPR][2 * EPV];
   __shared__ float tot[LPR][2 * EPV];
   __shared__ float sg[LPR][2];
@@ -664,12 +664,12 @@ extern "C" int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (const int cb = gn_fused_cb(HW, C, G, dtype, 8)) {
     const dim3 grid(N, C / cb);
-    const bool small = HW <= 2 * (1024 / (dtype == DT_F32 ? 16 : 8));   // passes per thread: 2 or 8
+    const int lpr = dtype == DT_F32 ? 16 : 8;
+    const int nthr = HW <= 8 * (256 / lpr) ? 256 : HW <= 8 * (512 / lpr) ? 512 : 1024;   // smallest block with <= 8 passes
 #define MDM_GN_FUSED_FWD(TT, ACT)                                                                                  \
-    if (small) hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, 2>), grid, dim3(1024), 0, st, (const TT*)x, gamma,  \
-                                  beta, (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps);                   \
-    else hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, 8>), grid, dim3(1024), 0, st, (const TT*)x, gamma, beta,  \
-                            (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps)
+    if (nthr == 256) hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, 8, 256>), grid, dim3(256), 0, st, (const TT*)x, gamma, beta, (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps); \
+    else if (nthr == 512) hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, 8, 512>), grid, dim3(512), 0, st, (const TT*)x, gamma, beta, (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps); \
+    else hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, 8, 1024>), grid, dim3(1024), 0, st, (const TT*)x, gamma, beta, (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps)
     if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_FWD(float, 1); } else { MDM_GN_FUSED_FWD(float, 0); } }
     else { if (act) { MDM_GN_FUSED_FWD(bf16, 1); } else { MDM_GN_FUSED_FWD(bf16, 0); } }
 #undef MDM_GN_FUSED_FWD
@@ -708,14 +708,11 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
   // x AND dy stay in registers here: 4 passes at most (beyond that the register file spills; three-kernel path)
   if (const int cb = gn_fused_cb(HW, C, G, dtype, 4)) {
     const dim3 grid(N, C / cb);
-    const bool small = HW <= 2 * (1024 / (dtype == DT_F32 ? 16 : 8));
+    const int lpr = dtype == DT_F32 ? 16 : 8;
+    const int nthr = HW <= 4 * (512 / lpr) ? 512 : 1024;
 #define MDM_GN_FUSED_BWD(TT, ACT)                                                                                  \
-    if (small) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 2>), grid, dim3(1024), 0, st, (const TT*)dy,        \
-                                  (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm,     \
-                                  pgrad, HW, C, G, cb);                                                             \
-    else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4>), grid, dim3(1024), 0, st, (const TT*)dy,              \
-                            (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, pgrad,    \
-                            HW, C, G, cb)
+    if (nthr == 512) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 512>), grid, dim3(512), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, pgrad, HW, C, G, cb); \
+    else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 1024>), grid, dim3(1024), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, pgrad, HW, C, G, cb)
     if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_BWD(float, 1); } else { MDM_GN_FUSED_BWD(float, 0); } }
     else { if (act) { MDM_GN_FUSED_BWD(bf16, 1); } else { MDM_GN_FUSED_BWD(bf16, 0); } }
 #undef MDM_GN_FUSED_BWD
