@@ -1712,32 +1712,51 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
 // workspace size (bytes) the caller must provide to mdm_conv_wgrad
 static int g_wgrad_big = -1;   // MDM_HIP_WGRAD_BIG=0 disables the 256x256 wgrad tile (A/B testing)
 
-// tile edge used for a problem: 256 for the bf16 8-wave kernel when both output dims reach it and the reduction
-// is long enough to amortise its larger prologue (measured: 3x3 layers +15-35 %, 1x1 layers at M = 16384 -25 %)
-static int wgrad_tile(int M, int Cout, int K, int dtype) {
+// Tile edge (128: 4 waves, 2 blocks / CU; 256: bf16 8-wave kernel, 1 block / CU) and split count of a problem, by a
+// small cost model in microseconds: rounds of resident blocks x (reduction tiles per split x tile time + per-block
+// prologue and slab write) + the slab traffic of the reduce kernel.  Replaces "about 2 blocks per CU": at
+// Cout x K = 768 x 3072 that rule gave 15 splits = 540 blocks = 2.1 rounds of the 256 CUs.
+static void wgrad_choose(int M, int Cout, int K, int dtype, int* te_out, int* splits_out) {
   if (g_wgrad_big < 0) {
     const char* e = getenv("MDM_HIP_WGRAD_BIG");
-    g_wgrad_big = e ? atoi(e) : 1;
+    g_wgrad_big = e ? atoi(e) : 1;   // 0: 128 only, 2: 256 whenever legal (A/B testing)
   }
-  return (dtype == DT_BF16 && g_wgrad_big && Cout >= 256 && K >= 256 && (K >= 2304 || M >= 65536)) ? 256 : 128;
+  const int bkm = dtype == DT_F32 ? 32 : 64;
+  const int mt_total = (M + bkm - 1) / bkm;
+  double best = 1e30;
+  int best_te = 128, best_s = 1;
+  for (int te = 128; te <= 256; te += 128) {
+    if (te == 256 && !(dtype == DT_BF16 && g_wgrad_big && Cout >= 192 && K >= 192)) continue;
+    if (te == 128 && g_wgrad_big == 2 && dtype == DT_BF16 && Cout >= 192 && K >= 192) continue;
+    const int tiles = ((Cout + te - 1) / te) * ((K + te - 1) / te);
+    const int slots = te == 256 ? 256 : 512;
+    const double t_tile = (te == 256 ? 1.7 : 1.06) * (dtype == DT_F32 ? 8.0 : 1.0), t_fix = te == 256 ? 12.0 : 5.0;
+    const int smax = mt_total < 64 ? mt_total : 64;
+    for (int sp = 1; sp <= smax; ++sp) {
+      const int per = (mt_total + sp - 1) / sp;
+      if ((mt_total + per - 1) / per != sp) continue;          // canonical split counts only
+      const long blocks = (long)tiles * sp;
+      const double rounds = (double)((blocks + slots - 1) / slots);
+      const double cost = rounds * (per * t_tile + t_fix) + sp * (double)Cout * K * 4.0 / 5.0e6 + (sp > 1 ? 4.0 : 0.0);
+      if (cost < best) { best = cost; best_te = te; best_s = sp; }
+    }
+  }
+  *te_out = best_te;
+  *splits_out = best_s;
+}
+
+static int wgrad_tile(int M, int Cout, int K, int dtype) {
+  int te, sp;
+  wgrad_choose(M, Cout, K, dtype, &te, &sp);
+  return te;
 }
 
 extern "C" int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype) { return wgrad_tile(M, Cout, K, dtype); }
 
 extern "C" int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes) {
   MDM_CHECK_ARG(splits_out && ws_bytes);
-  const int bkm = dtype == DT_F32 ? 32 : 64;
-  const int te = wgrad_tile(M, Cout, K, dtype);
-  const int tiles = ((Cout + te - 1) / te) * ((K + te - 1) / te);
-  const int mt_total = (M + bkm - 1) / bkm;
-  const int target = te == 256 ? 512 : 1024;           // workgroups: 1 (256^2) or 2 (128^2) resident per CU
-  int splits = (target + tiles - 1) / tiles;
-  if (splits > mt_total) splits = mt_total;
-  const int max_by_work = (mt_total + 7) / 8;          // >= 8 reduction tiles per split
-  if (splits > max_by_work) splits = max_by_work;
-  if (splits < 1) splits = 1;
-  const int per = (mt_total + splits - 1) / splits;
-  splits = (mt_total + per - 1) / per;
+  int te, splits;
+  wgrad_choose(M, Cout, K, dtype, &te, &splits);
   *splits_out = splits;
   // weight slabs + bias-gradient partials (or the column-sum workspace of the fp32 path)
   *ws_bytes = ((size_t)splits * Cout * K + (size_t)(splits > 64 ? splits : 64) * Cout) * sizeof(float);
