@@ -21,6 +21,8 @@
 // are read in the permuted order key(kt, r) = (kt>>1)*32 + (r>>2)*8 + (kt&1)*4 + (r&3)
 // so that a lane's 8 probabilities of one PV step are 8 *contiguous* keys of the
 // transposed V tile.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mdm {
@@ -109,6 +111,35 @@ __device__ __forceinline__ void load_tr_tile(char* dst, const T* src, int rs, in
   }
 }
 
+// The same natural tile in two steps, so the global loads of the NEXT tile can be in flight while the MFMAs of the
+// current one run: fetch (HBM -> registers) ... compute ... commit (registers -> LDS).
+template <typename T, int D> struct NatRegs { uint4 v[(64 * AttnGeom<T, D>::CPR + 255) / 256]; };
+template <typename T, int D>
+__device__ __forceinline__ void fetch_nat(NatRegs<T, D>& r, const T* src, int rs, int row0, int nrows, int tid) {
+  using G = AttnGeom<T, D>;
+  constexpr int NV = (64 * G::CPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c / G::CPR, cc = c - row * G::CPR;
+    const bool ok = c < 64 * G::CPR && row0 + row < nrows;
+    uint4 val = *reinterpret_cast<const uint4*>(src + (ok ? (size_t)(row0 + row) * rs + cc * G::EPV : (size_t)0));
+    val.x = ok ? val.x : 0u; val.y = ok ? val.y : 0u; val.z = ok ? val.z : 0u; val.w = ok ? val.w : 0u;
+    r.v[i] = val;
+  }
+}
+template <typename T, int D>
+__device__ __forceinline__ void commit_nat(char* dst, const NatRegs<T, D>& r, int tid) {
+  using G = AttnGeom<T, D>;
+  constexpr int NV = (64 * G::CPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c / G::CPR, cc = c - row * G::CPR;
+    if (c < 64 * G::CPR) *reinterpret_cast<uint4*>(dst + (cc >> 3) * (64 * 128) + lds_chunk_off(row, cc & 7)) = r.v[i];
+  }
+}
+
 // Fragment whose rows are CHANNELS (d index c16*16 + l16) and whose 8 reduction slots are tile ROWS
 // hh*32 + quad*8 + [0, 8) -- i.e. a fragment of the transposed tile.
 //   bf16: read from the NATURAL [row][d] image with the LDS transpose read (lane i of a 16-lane group supplies
@@ -149,8 +180,12 @@ __device__ __forceinline__ int perm_row(int kt, int r) { return (kt >> 1) * 32 +
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <typename T, int D, int QT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+// OCM (out_cross in memory): the cross softmax runs FIRST and its normalised result goes to p.out_cross; the final
+// store re-reads it (same lane, L2-warm) and adds the self part -- so no second accumulator set lives across the
+// long self loop (48 registers at d = 96: one more resident wave per SIMD).  Without an out_cross buffer the sum
+// is kept in registers.
+template <typename T, int D, int QT, bool OCM>
+__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
   using G = AttnGeom<T, D>;
   constexpr int KSTEPS = G::KSTEPS, DS = G::DS, DT = G::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -171,14 +206,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     for (int ks = 0; ks < DS; ++ks) frag_from_global<T>(qf[qt][ks], Q + (size_t)qi * p.q_rs + ks * 32 + quad * 8, qi < p.L);
   }
 
-  f32x4 res[QT][DT];
+  f32x4 res[OCM ? 1 : QT][OCM ? 1 : DT];
+  if constexpr (!OCM) {
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) res[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int dt = 0; dt < DT; ++dt) res[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
+  const float c2 = p.scale * 1.4426950408889634f;   // scores -> base-2 exponent
   const int npass = p.kc ? 2 : 1;
-  for (int pass = 0; pass < npass; ++pass) {
+  for (int ipass = 0; ipass < npass; ++ipass) {
+    const int pass = npass - 1 - ipass;   // cross keys first, self keys last
     const T* Kp = reinterpret_cast<const T*>(pass ? p.kc : p.k) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
     const T* Vp = reinterpret_cast<const T*>(pass ? p.vc : p.v) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
     const int rs = pass ? p.c_rs : p.k_rs;
@@ -194,11 +233,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // bf16: double-buffered NATURAL K and V tiles (V^T fragments come from the LDS transpose read), the next tile's
+    // global loads issued before this tile's MFMAs and committed to the other buffer after them; one barrier / tile.
+    // fp32: K natural + V transposed, staged synchronously (ds_read_tr is a 16-bit instruction).
+    constexpr bool PF = sizeof(T) == 2;
+    NatRegs<T, D> kr, vr;
+    int it = 0;
+    if constexpr (PF) {
+      __syncthreads();   // the previous pass may still be reading buffer 0
+      fetch_nat<T, D>(kr, Kp, rs, 0, nk, tid);
+      fetch_nat<T, D>(vr, Vp, rs, 0, nk, tid);
+      commit_nat<T, D>(smem, kr, tid);
+      commit_nat<T, D>(smem + G::NAT_BYTES, vr, tid);
+    }
     for (int k0 = 0; k0 < nk; k0 += 64) {
       __syncthreads();
-      load_nat_tile<T, D>(Ks, Kp, rs, k0, nk, tid);
-      load_tr_tile<T, D>(Vs, Vp, rs, k0, nk, tid);
-      __syncthreads();
+      if constexpr (PF) {
+        Ks = smem + (it & 1) * (2 * G::NAT_BYTES);
+        Vs = Ks + G::NAT_BYTES;
+        if (k0 + 64 < nk) {
+          fetch_nat<T, D>(kr, Kp, rs, k0 + 64, nk, tid);
+          fetch_nat<T, D>(vr, Vp, rs, k0 + 64, nk, tid);
+        }
+      } else {
+        load_nat_tile<T, D>(Ks, Kp, rs, k0, nk, tid);
+        load_tr_tile<T, D>(Vs, Vp, rs, k0, nk, tid);
+        __syncthreads();
+      }
 
       f32x4 s[QT][4];
 #pragma unroll
@@ -214,37 +275,42 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
           for (int ks = 0; ks < DS; ++ks) mma16(s[qt][kt], kf[ks], qf[qt][ks]);
         }
       }
-      // scale + mask.  lane holds key positions (kt>>1)*32 + quad*8 + (kt&1)*4 + i
+      // Softmax in the base-2 domain: t = s * (scale * log2 e), running max m_run and sum l_run per query column;
+      // p = 2^(t - m) is one fma + one v_exp_f32.  A full, unmasked tile (the common case) needs no per-key predicate.
+      // lane holds key positions (kt>>1)*32 + quad*8 + (kt&1)*4 + i
+      const bool full = (k0 + 64 <= nk) && !mrow;   // block-uniform
+      if (!full) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int key = k0 + (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
-          bool ok = key < nk;
-          if (ok && mrow) ok = mrow[key] != 0.f;
+          for (int i = 0; i < 4; ++i) {
+            const int key = k0 + (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
+            bool ok = key < nk;
+            if (ok && mrow) ok = mrow[key] != 0.f;
 #pragma unroll
-          for (int qt = 0; qt < QT; ++qt) s[qt][kt][i] = ok ? s[qt][kt][i] * p.scale : -1e30f;
-        }
+            for (int qt = 0; qt < QT; ++qt) s[qt][kt][i] = ok ? s[qt][kt][i] : -3.0e38f;
+          }
+      }
       Frag<T> pf[QT][2];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
-        float mx = -1e30f;
+        float mx = -3.0e38f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[qt][kt][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[qt], mx);
-        const float alpha = __expf(m_run[qt] - m_new);
+        const float m_new = fmaxf(m_run[qt], fmaxf(mx * c2, -1e30f));   // a fully masked tile leaves m_run alone
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
         m_run[qt] = m_new;
         float ls = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float sv = s[qt][kt][i];
-            const float e = sv > -1e29f ? __expf(sv - m_new) : 0.f;
+            // masked scores are -3e38: the fma saturates to -inf and 2^-inf = 0
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][i], c2, -m_new));
             s[qt][kt][i] = e; ls += e;
           }
         l_run[qt] = l_run[qt] * alpha + ls;
@@ -258,15 +324,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           Frag<T> vf;
-          load_frag<T>(vf, Vs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
+          if constexpr (PF) load_frag_T<T, D>(vf, Vs, nullptr, dt, hh, quad, l16);
+          else load_frag<T>(vf, Vs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) mma16(o[qt][dt], vf, pf[qt][hh]);
         }
+      if constexpr (PF) {
+        if (k0 + 64 < nk) {
+          char* nb = smem + ((it + 1) & 1) * (2 * G::NAT_BYTES);
+          commit_nat<T, D>(nb, kr, tid);
+          commit_nat<T, D>(nb + G::NAT_BYTES, vr, tid);
+        }
+        ++it;
+      }
     }
 
     // finalise this softmax
     T* OC = (pass && p.out_cross) ? reinterpret_cast<T*>(p.out_cross) + (size_t)b * p.o_bs + (size_t)h * D : nullptr;
     float* LSE = pass ? p.lse_cross : p.lse_self;
+    T* O = reinterpret_cast<T*>(p.out) + (size_t)b * p.o_bs + (size_t)h * D;
+    const T* OCR = (OCM && p.kc) ? reinterpret_cast<const T*>(p.out_cross) + (size_t)b * p.o_bs + (size_t)h * D : nullptr;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float l = l_run[qt];
@@ -274,30 +351,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       l += __shfl_xor(l, 32, 64);
       const float inv = l > 0.f ? 1.f / l : 0.f;
       const int qi = q0 + qt * 16 + l16;
-      if (LSE && quad == 0 && qi < p.L) LSE[((size_t)b * p.H + h) * p.L + qi] = m_run[qt] + __logf(l);
+      if (LSE && quad == 0 && qi < p.L) LSE[((size_t)b * p.H + h) * p.L + qi] = m_run[qt] * 0.6931471805599453f + __logf(l);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const f32x4 val = o[qt][dt] * inv;
-        res[qt][dt] += val;
+        f32x4 val = o[qt][dt] * inv;
         if (OC && qi < p.L) {
           T* dst = OC + (size_t)qi * p.o_rs + dt * 16 + quad * 4;
 #pragma unroll
           for (int i = 0; i < 4; ++i) dst[i] = from_f32<T>(val[i]);
         }
+        if constexpr (!OCM) {
+          res[qt][dt] += val;
+          val = res[qt][dt];
+        }
+        if (pass == 0 && qi < p.L) {   // last pass: the output row
+          T* dst = O + (size_t)qi * p.o_rs + dt * 16 + quad * 4;
+          if (OCM && OCR) {
+            const T* src = OCR + (size_t)qi * p.o_rs + dt * 16 + quad * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) val[i] += to_f32(src[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dst[i] = from_f32<T>(val[i]);
+        }
       }
-    }
-  }
-
-  T* O = reinterpret_cast<T*>(p.out) + (size_t)b * p.o_bs + (size_t)h * D;
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int qi = q0 + qt * 16 + l16;
-    if (qi >= p.L) continue;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      T* dst = O + (size_t)qi * p.o_rs + dt * 16 + quad * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dst[i] = from_f32<T>(res[qt][dt][i]);
     }
   }
 }
@@ -349,7 +426,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ d
 // backward, dQ:   dS^T = P^T o (V dO^T - delta),  dQ^T = K^T dS^T  (both softmaxes accumulate)
 // ---------------------------------------------------------------------------------------
 template <typename T, int D, int QT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
   using G = AttnGeom<T, D>;
   constexpr int KSTEPS = G::KSTEPS, DS = G::DS, DT = G::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -379,6 +456,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float c2 = p.scale * 1.4426950408889634f;
 
   const int npass = p.kc ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
@@ -393,15 +471,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       const int qi = q0 + qt * 16 + l16;
-      lse[qt] = qi < p.L ? LSE[qi] : 1e30f;
+      lse[qt] = (qi < p.L ? LSE[qi] : 1e30f) * 1.4426950408889634f;   // base-2 domain: p = 2^(s * c2 - lse2)
       del[qt] = qi < p.L ? DEL[qi] : 0.f;
+    }
+    // bf16: double-buffered K / V tiles with the next tile's global loads in flight during the MFMAs (see forward)
+    constexpr bool PF = sizeof(T) == 2;
+    NatRegs<T, D> kr, vr;
+    int it = 0;
+    if constexpr (PF) {
+      __syncthreads();
+      fetch_nat<T, D>(kr, Kp, rs, 0, nk, tid);
+      fetch_nat<T, D>(vr, Vp, rs, 0, nk, tid);
+      commit_nat<T, D>(smem, kr, tid);
+      commit_nat<T, D>(smem + G::NAT_BYTES, vr, tid);
     }
     for (int k0 = 0; k0 < nk; k0 += 64) {
       __syncthreads();
-      load_nat_tile<T, D>(Ks, Kp, rs, k0, nk, tid);
-      load_nat_tile<T, D>(Vs, Vp, rs, k0, nk, tid);
-      if constexpr (sizeof(T) != 2) load_tr_tile<T, D>(KTs, Kp, rs, k0, nk, tid);
-      __syncthreads();
+      if constexpr (PF) {
+        Ks = smem + (it & 1) * (2 * G::NAT_BYTES);
+        Vs = Ks + G::NAT_BYTES;
+        if (k0 + 64 < nk) {
+          fetch_nat<T, D>(kr, Kp, rs, k0 + 64, nk, tid);
+          fetch_nat<T, D>(vr, Vp, rs, k0 + 64, nk, tid);
+        }
+      } else {
+        load_nat_tile<T, D>(Ks, Kp, rs, k0, nk, tid);
+        load_nat_tile<T, D>(Vs, Vp, rs, k0, nk, tid);
+        load_tr_tile<T, D>(KTs, Kp, rs, k0, nk, tid);
+        __syncthreads();
+      }
       f32x4 s[QT][4], dp[QT][4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
@@ -423,19 +521,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
           }
         }
       }
+      if ((k0 + 64 <= nk) && !mrow) {   // full, unmasked tile (block-uniform): no per-key predicate
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int key = k0 + (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
-          bool ok = key < nk;
-          if (ok && mrow) ok = mrow[key] != 0.f;
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int qt = 0; qt < QT; ++qt) {
-            const float pr = ok ? __expf(s[qt][kt][i] * p.scale - lse[qt]) : 0.f;
-            s[qt][kt][i] = pr * (dp[qt][kt][i] - del[qt]);
+            for (int qt = 0; qt < QT; ++qt) {
+              const float pr = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][i], c2, -lse[qt]));
+              s[qt][kt][i] = pr * (dp[qt][kt][i] - del[qt]);
+            }
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int key = k0 + (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
+            bool ok = key < nk;
+            if (ok && mrow) ok = mrow[key] != 0.f;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+              const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[qt][kt][i], c2, -lse[qt])) : 0.f;
+              s[qt][kt][i] = pr * (dp[qt][kt][i] - del[qt]);
+            }
           }
-        }
+      }
       Frag<T> dsf[QT][2];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
@@ -451,6 +561,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) mma16(dq[qt][dt], ktf, dsf[qt][hh]);
         }
+      if constexpr (PF) {
+        if (k0 + 64 < nk) {
+          char* nb = smem + ((it + 1) & 1) * (2 * G::NAT_BYTES);
+          commit_nat<T, D>(nb, kr, tid);
+          commit_nat<T, D>(nb + G::NAT_BYTES, vr, tid);
+        }
+        ++it;
+      }
     }
   }
   T* DQ = reinterpret_cast<T*>(p.dq) + (size_t)b * p.q_bs + (size_t)h * D;
@@ -474,7 +592,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 //   dV^T = dO^T P,  dK^T = Q^T dS
 // ---------------------------------------------------------------------------------------
 template <typename T, int D, int KT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
   // KT = 16-key tiles per wave: the block owns 64 * KT keys; the Q / dO fragments of a query tile are read from LDS
   // once and reused for every key tile of the wave (KT = 2 halves the tile loads and LDS reads per key)
   using G = AttnGeom<T, D>;
@@ -517,26 +635,58 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
   const float* LSE = (pass ? p.lse_cross : p.lse_self) + ((size_t)b * p.H + h) * p.L;
   const float* DEL = (pass ? p.delta_cross : p.delta_self) + ((size_t)b * p.H + h) * p.L;
 
+  const float c2 = p.scale * 1.4426950408889634f;
   f32x4 dk[KT][DT], dv[KT][DT];
 #pragma unroll
   for (int kk = 0; kk < KT; ++kk)
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { dk[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+  // bf16: double-buffered Q / dO tiles (+ their lse / delta rows), next tile's global loads in flight during the MFMAs
+  constexpr bool PF = sizeof(T) == 2;
+  constexpr int BUF = 2 * G::NAT_BYTES + 512;   // one stage: Q, dO, lse[64], delta[64]
+  NatRegs<T, D> qr, gr;
+  float lse_r = 0.f, del_r = 0.f;
+  int it = 0;
+  if constexpr (PF) {
+    fetch_nat<T, D>(qr, Q, p.q_rs, 0, p.L, tid);
+    fetch_nat<T, D>(gr, DO, p.o_rs, 0, p.L, tid);
+    commit_nat<T, D>(smem, qr, tid);
+    commit_nat<T, D>(smem + G::NAT_BYTES, gr, tid);
+    if (tid < 64) {
+      float* ls = reinterpret_cast<float*>(smem + 2 * G::NAT_BYTES);
+      ls[tid] = (tid < p.L ? LSE[tid] : 1e30f) * 1.4426950408889634f;
+      ls[64 + tid] = tid < p.L ? DEL[tid] : 0.f;
+    }
+  }
   for (int q0 = 0; q0 < p.L; q0 += 64) {
     __syncthreads();
-    load_nat_tile<T, D>(Qs, Q, p.q_rs, q0, p.L, tid);
-    load_nat_tile<T, D>(Gs, DO, p.o_rs, q0, p.L, tid);
-    if constexpr (sizeof(T) != 2) {
+    if constexpr (PF) {
+      Qs = smem + (it & 1) * BUF;
+      Gs = Qs + G::NAT_BYTES;
+      lse_s = reinterpret_cast<float*>(Qs + 2 * G::NAT_BYTES);
+      del_s = lse_s + 64;
+      if (q0 + 64 < p.L) {
+        fetch_nat<T, D>(qr, Q, p.q_rs, q0 + 64, p.L, tid);
+        fetch_nat<T, D>(gr, DO, p.o_rs, q0 + 64, p.L, tid);
+        if (tid < 64) {
+          const int qi = q0 + 64 + tid;
+          lse_r = (qi < p.L ? LSE[qi] : 1e30f) * 1.4426950408889634f;
+          del_r = qi < p.L ? DEL[qi] : 0.f;
+        }
+      }
+    } else {
+      load_nat_tile<T, D>(Qs, Q, p.q_rs, q0, p.L, tid);
+      load_nat_tile<T, D>(Gs, DO, p.o_rs, q0, p.L, tid);
       load_tr_tile<T, D>(QTs, Q, p.q_rs, q0, p.L, tid);
       load_tr_tile<T, D>(GTs, DO, p.o_rs, q0, p.L, tid);
+      if (tid < 64) {
+        const int qi = q0 + tid;
+        lse_s[tid] = (qi < p.L ? LSE[qi] : 1e30f) * 1.4426950408889634f;   // base-2 domain
+        del_s[tid] = qi < p.L ? DEL[qi] : 0.f;
+      }
+      __syncthreads();
     }
-    if (tid < 64) {
-      const int qi = q0 + tid;
-      lse_s[tid] = qi < p.L ? LSE[qi] : 1e30f;
-      del_s[tid] = qi < p.L ? DEL[qi] : 0.f;
-    }
-    __syncthreads();
     f32x4 s[KT][4], dp[KT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -565,7 +715,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int qp = (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
-          const float pv = key_live[kk] ? __expf(s[kk][kt][i] * p.scale - lse_s[qp]) : 0.f;
+          const float pv = key_live[kk] ? __builtin_amdgcn_exp2f(fmaf(s[kk][kt][i], c2, -lse_s[qp])) : 0.f;
           pr[kt][i] = pv;
           s[kk][kt][i] = pv * (dp[kk][kt][i] - del_s[qp]);
         }
@@ -587,6 +737,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
           mma16(dk[kk][dt], a, dsf[kk][hh]);
         }
       }
+    if constexpr (PF) {
+      if (q0 + 64 < p.L) {
+        char* nb = smem + ((it + 1) & 1) * BUF;
+        commit_nat<T, D>(nb, qr, tid);
+        commit_nat<T, D>(nb + G::NAT_BYTES, gr, tid);
+        if (tid < 64) {
+          float* ls = reinterpret_cast<float*>(nb + 2 * G::NAT_BYTES);
+          ls[tid] = lse_r;
+          ls[64 + tid] = del_r;
+        }
+      }
+      ++it;
+    }
   }
 #pragma unroll
   for (int kk = 0; kk < KT; ++kk) {
@@ -615,29 +778,48 @@ static void set_smem(K kern, int bytes) {
 template <typename T, int D>
 static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   using G = AttnGeom<T, D>;
-  constexpr int QT = 2;
-  constexpr int smem = G::NAT_BYTES + (G::NAT_BYTES > G::TR_BYTES ? G::NAT_BYTES : G::TR_BYTES);
-  auto kern = attn_fwd_kernel<T, D, QT>;
+  constexpr int smem = sizeof(T) == 2 ? 4 * G::NAT_BYTES : G::NAT_BYTES + (G::NAT_BYTES > G::TR_BYTES ? G::NAT_BYTES : G::TR_BYTES);
+  static int qt_env = -1;
+  if (qt_env < 0) { const char* e = getenv("MDM_HIP_ATTN_QT"); qt_env = e ? atoi(e) : 2; }   // queries per wave / 16 (A/B testing)
   static bool done = false;
-  if (!done) { set_smem(kern, smem); done = true; }
-  dim3 grid((a.L + 64 * QT - 1) / (64 * QT), a.B * a.H);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  if (!done) {
+    set_smem(attn_fwd_kernel<T, D, 2, true>, smem); set_smem(attn_fwd_kernel<T, D, 2, false>, smem);
+    set_smem(attn_fwd_kernel<T, D, 1, true>, smem); set_smem(attn_fwd_kernel<T, D, 1, false>, smem);
+    done = true;
+  }
+  const bool ocm = !a.kc || a.out_cross;   // nothing to keep, or a buffer to keep it in
+  if (qt_env == 1) {
+    dim3 grid((a.L + 63) / 64, a.B * a.H);
+    if (ocm) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, true>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, false>), grid, dim3(256), smem, st, a);
+  } else {
+    dim3 grid((a.L + 127) / 128, a.B * a.H);
+    if (ocm) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, true>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, false>), grid, dim3(256), smem, st, a);
+  }
   MDM_LAUNCH_STATUS();
 }
 
 template <typename T, int D>
 static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int dc_rs, hipStream_t st) {
   using G = AttnGeom<T, D>;
-  constexpr int QT = 2;
-  constexpr int smem_q = 2 * G::NAT_BYTES + G::TR_BYTES;
-  constexpr int smem_kv = 2 * G::NAT_BYTES + 2 * G::TR_BYTES + 512;
-  auto kq = attn_bwd_dq_kernel<T, D, QT>;
+  constexpr int smem_q = sizeof(T) == 2 ? 4 * G::NAT_BYTES : 2 * G::NAT_BYTES + G::TR_BYTES;
+  constexpr int smem_kv = sizeof(T) == 2 ? 2 * (2 * G::NAT_BYTES + 512) : 2 * G::NAT_BYTES + 2 * G::TR_BYTES + 512;
   auto kkv = attn_bwd_dkv_kernel<T, D, 1>;
   constexpr int KTS = 1;   // 2 key tiles per wave measured SLOWER (286-331 registers -> 1 wave / SIMD): 2.18 vs 1.59 ms
   auto kkv2 = attn_bwd_dkv_kernel<T, D, KTS>;
+  // queries per wave of the dQ kernel: 32 (QT = 2) reuses each K / V fragment twice; at d = 96 its two operand sets
+  // (Q, dO) + two score tiles no longer fit 256 registers, so 16 (QT = 1, three waves per SIMD) wins there
+  static int qt_env = -1;
+  if (qt_env < 0) { const char* e = getenv("MDM_HIP_ATTN_DQ_QT"); qt_env = e ? atoi(e) : (D >= 96 ? 1 : 2); }
   static bool done = false;
-  if (!done) { set_smem(kq, smem_q); set_smem(kkv, smem_kv); set_smem(kkv2, smem_kv); done = true; }
-  hipLaunchKernelGGL(kq, dim3((a.L + 64 * QT - 1) / (64 * QT), a.B * a.H), dim3(256), smem_q, st, a);
+  if (!done) {
+    set_smem(attn_bwd_dq_kernel<T, D, 1>, smem_q); set_smem(attn_bwd_dq_kernel<T, D, 2>, smem_q);
+    set_smem(kkv, smem_kv); set_smem(kkv2, smem_kv);
+    done = true;
+  }
+  if (qt_env == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 1>), dim3((a.L + 63) / 64, a.B * a.H), dim3(256), smem_q, st, a);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 2>), dim3((a.L + 127) / 128, a.B * a.H), dim3(256), smem_q, st, a);
   a.pass = 0;
   if (a.L >= 128) hipLaunchKernelGGL(kkv2, dim3((a.L + 64 * KTS - 1) / (64 * KTS), a.B * a.H), dim3(256), smem_kv, st, a);
   else hipLaunchKernelGGL(kkv, dim3((a.L + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);

@@ -572,7 +572,7 @@ class AttentionFn(torch.autograd.Function):
         out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=qkv.device)
         lse_s = torch.empty((B, heads, L), dtype=torch.float32, device=qkv.device) if keep else None
         lse_c = torch.empty((B, heads, L), dtype=torch.float32, device=qkv.device) if (keep and kvc is not None) else None
-        oc = torch.empty_like(out) if (keep and kvc is not None) else None
+        oc = torch.empty_like(out) if kvc is not None else None   # also the kernel's staging buffer for the cross part
         _lib.check(
             _lib.lib().mdm_attn_fwd(_p(qkv), _p(kvc), _p(m32), _p(out), _p(oc), _p(lse_s), _p(lse_c), B, L, S, heads, d, _dt(qkv), _stream()),
             "mdm_attn_fwd",
