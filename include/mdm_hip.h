@@ -34,6 +34,9 @@ enum { MDM_ACT_NONE = 0, MDM_ACT_GELU = 1, MDM_ACT_DGELU_AUX = 2 };
 
 int mdm_abi_version(void);
 const char* mdm_last_error(void);
+/* Name (as a profiler prints it, without arguments) of the GEMM-class kernel the calling thread launched last;
+ * bench.py uses it to label per-launch HIP-event timings.  Development aid, not part of the reference surface. */
+const char* mdm_last_gemm_kernel(void);
 
 /* ---- convolution / linear (implicit GEMM on MFMA) --------------------------------------
  * replaces nn.Conv2d 3x3 s1/s2 p1 and 1x1 (models/unet.py:199-221, 260-271, 514-532, 632, 751;

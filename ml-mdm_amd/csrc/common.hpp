@@ -174,10 +174,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division: "a / b" expands to an 11-instruction div_scale / div_fmas /
+// div_fixup sequence, which made the activation the most expensive part of the epilogues that apply it
+__device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float silu_f(float z) { return z * rcp_f(1.f + __expf(-z)); }
 // d silu(z) / dz
 __device__ __forceinline__ float dsilu_f(float z) {
-  float s = 1.f / (1.f + __expf(-z));
+  float s = rcp_f(1.f + __expf(-z));
   return s * (1.f + z * (1.f - s));
 }
 // exact (erf) GELU, nn.GELU() default (unet.py:270).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
@@ -187,10 +190,10 @@ __device__ __forceinline__ float dsilu_f(float z) {
 __device__ __forceinline__ void gauss_cdf_pdf(float z, float& cdf, float& pdf) {
   const float az = fabsf(z) * 0.70710678118654752f;          // |z| / sqrt(2)
   const float e = __expf(-az * az);                            // e^{-z^2/2}
-  const float t = __frcp_rn(1.f + 0.3275911f * az);
+  const float t = rcp_f(1.f + 0.3275911f * az);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.f - poly * e;                        // erf(|z|/sqrt 2)
-  cdf = 0.5f * (1.f + copysignf(erf_abs, z));
+  cdf = fmaf(0.5f, copysignf(erf_abs, z), 0.5f);
   pdf = 0.3989422804014327f * e;
 }
 __device__ __forceinline__ float gelu_f(float z) {

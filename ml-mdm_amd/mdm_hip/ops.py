@@ -202,6 +202,9 @@ def _prof_wrap(name, flops, fn):
     e0.record()
     r = fn()
     e1.record()
+    real = _lib.lib().mdm_last_gemm_kernel()   # the kernel that actually ran (name as rocprofv3 prints it)
+    if real:
+        name = real.decode() + (name[name.index(" M="):] if " M=" in name else "")
     _prof.append((name, flops, e0, e1))
     return r
 
