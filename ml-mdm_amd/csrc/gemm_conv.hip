@@ -63,9 +63,13 @@ __device__ __attribute__((aligned(16))) uint4 g_zero_page[4] = {};
 // Epilogue shared by the GEMM kernels: bias / activation / residual in registers (fp32), then the finished tile is
 // staged through LDS (free after the k-loop, LDS_BYTES of it) so that HBM sees whole 16-byte chunks of complete
 // output rows instead of the 8-byte-per-lane fragments of the MFMA layout.
-template <typename T, int BM, int BN, int WM, int WN, int LDS_BYTES>
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+
+// `after_lds` runs once every wave is done with the LDS (the staged tile is in registers by then): a persistent
+// kernel issues the next tile's first LDS-DMA there, so those loads overlap this tile's stores.
+template <typename T, int BM, int BN, int WM, int WN, int LDS_BYTES, typename AfterLds = NoPrefetch>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
-                                              int m0, int n0) {
+                                              int m0, int n0, AfterLds after_lds = AfterLds()) {
   constexpr int EPV = Tr<T>::EPV;
   constexpr int NT_ = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -76,7 +80,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
   // bias / activation / residual are applied in registers (fp32); the finished tile is then staged through
   // LDS (free after the k-loop) so that HBM sees whole 16-byte chunks of complete output rows instead of the
   // 8-byte-per-lane fragments of the MFMA layout (the output-heavy 1x1 convs -- qkv, FFN up -- were store-bound).
-  if (p.dbg & 8) return;
+  if (p.dbg & 8) { __syncthreads(); after_lds(); return; }
   T* __restrict__ Y = reinterpret_cast<T*>(p.y);
   T* __restrict__ Ypre = reinterpret_cast<T*>(p.ypre);
   const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
@@ -121,21 +125,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
     //    (conv output in bf16, then GELU / add as separate bf16 ops); in fp32 mode nothing is rounded.
     const int act = p.act;
     const bool skip_store = (p.dbg & 4) != 0;
-#pragma unroll 4
-    for (int idx = tid; idx < BM * OCH; idx += NT_) {
+    constexpr int NCH = BM * OCH / NT_;   // staged chunks per thread
+    static_assert(NCH * NT_ == BM * OCH, "staged tile must divide evenly over the block");
+    uint4 raw[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + i * NT_;
+      const int row = idx / OCH, ch = idx - row * OCH;
+      raw[i] = *reinterpret_cast<const uint4*>(smem + row * PITCH + ((ch ^ (row & SWZ)) << 4));
+    }
+    __syncthreads();   // the LDS is free again
+    after_lds();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + i * NT_;
       const int row = idx / OCH, ch = idx - row * OCH;
       const int m = m0 + row, n = n0 + ch * EPV;
       if (m >= p.M || n >= p.Cout || skip_store) continue;
       const size_t o = (size_t)m * p.Cout + n;
-      const uint4 raw = *reinterpret_cast<const uint4*>(smem + row * PITCH + ((ch ^ (row & SWZ)) << 4));
       if (act == 0 && !R) {
-        *reinterpret_cast<uint4*>(Y + o) = raw;
+        *reinterpret_cast<uint4*>(Y + o) = raw[i];
         continue;
       }
       Chunk<T> c;
-      c.load(reinterpret_cast<const T*>(&raw));
+      c.load(reinterpret_cast<const T*>(&raw[i]));
       if (act == 1) {
-        if (Ypre) *reinterpret_cast<uint4*>(Ypre + o) = raw;
+        if (Ypre) *reinterpret_cast<uint4*>(Ypre + o) = raw[i];
 #pragma unroll
         for (int e = 0; e < EPV; ++e) c.v[e] = gelu_f(c.v[e]);
       } else if (act == 2) {
@@ -154,6 +169,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
     }
     return;
   }
+  __syncthreads();
+  after_lds();
   // generic path (Cout not a multiple of the chunk): per-element stores
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -442,43 +459,48 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   const int wm = wave / WN, wn = wave % WN;
   const int quad = lane >> 4, l16 = lane & 15;
 
+  // Persistent blocks: block b works through output tiles b, b + G, b + 2G, ... (G = gridDim.x <= resident blocks);
+  // within each group of G the XCD-aware remap keeps neighbouring tiles (shared operand panels) on one XCD's L2.
   const int tiles_n = (p.Cout + BN - 1) / BN;
-  const int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+  const int tiles_total = ((p.M + BM - 1) / BM) * tiles_n;
+  const int G = gridDim.x;
+  const int b_in_group = xcd_remap(blockIdx.x, G);
 
-  // ---- per-lane gather offsets (bytes), fixed for the whole k-loop -------------
+  // ---- per-lane gather offsets (bytes) of one output tile, fixed for its whole k-loop -------------
   const int lrow = tid >> 3;
   const int lchunk = (tid & 7) ^ (lrow & 7);   // logical chunk this lane fetches (physical slot = tid & 7)
   const unsigned bias = MODE == MODE_3x3 ? (unsigned)(p.W + 1) * p.Cin * 2u : 0u;   // base shift that keeps the per-tap scalar offset non-negative
   unsigned a_voff[AJ], a_mask[AJ], b_voff[BJ];
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) {
-    const int m = m0 + lrow + RPP * j;
-    a_voff[j] = INVALID; a_mask[j] = 0u;
-    if (m < p.M) {
-      if (MODE == MODE_1x1) {
-        a_voff[j] = (unsigned)m * p.Cin * 2u + lchunk * 16u;
-        a_mask[j] = 0x1ffu;
-      } else {
-        const int hw = p.Ho * p.Wo;
-        const int n = m / hw, r = m - n * hw;
-        const int oh = r / p.Wo, ow = r - oh * p.Wo;
-        const int ih0 = oh * p.stride, iw0 = ow * p.stride;
-        a_voff[j] = (unsigned)(n * p.H * p.W + ih0 * p.W + iw0) * p.Cin * 2u + lchunk * 16u;   // relative to a_base = x - bias
-        unsigned mk = 0u;
-#pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-          const int ih = ih0 + tp / 3 - 1, iw = iw0 + tp % 3 - 1;
-          if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mk |= 1u << tp;
-        }
-        a_mask[j] = mk;
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) {
-    const int n = n0 + lrow + RPP * j;
-    b_voff[j] = n < p.Cout ? (unsigned)n * p.K * 2u + lchunk * 16u : INVALID;
+  int m0 = 0, n0 = 0;
+#define MDM_TILE_SETUP(tile_)                                                                               \
+  {                                                                                                         \
+    m0 = ((tile_) / tiles_n) * BM; n0 = ((tile_) % tiles_n) * BN;                                           \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                        \
+      const int m = m0 + lrow + RPP * j;                                                                    \
+      a_voff[j] = INVALID; a_mask[j] = 0u;                                                                  \
+      if (m < p.M) {                                                                                        \
+        if (MODE == MODE_1x1) {                                                                             \
+          a_voff[j] = (unsigned)m * p.Cin * 2u + lchunk * 16u;                                              \
+          a_mask[j] = 0x1ffu;                                                                               \
+        } else {                                                                                            \
+          const int hw = p.Ho * p.Wo;                                                                       \
+          const int n = m / hw, r = m - n * hw;                                                             \
+          const int oh = r / p.Wo, ow = r - oh * p.Wo;                                                      \
+          const int ih0 = oh * p.stride, iw0 = ow * p.stride;                                               \
+          a_voff[j] = (unsigned)(n * p.H * p.W + ih0 * p.W + iw0) * p.Cin * 2u + lchunk * 16u;              \
+          unsigned mk = 0u;                                                                                 \
+          _Pragma("unroll") for (int tp = 0; tp < 9; ++tp) {                                                \
+            const int ih = ih0 + tp / 3 - 1, iw = iw0 + tp % 3 - 1;                                         \
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mk |= 1u << tp;               \
+          }                                                                                                 \
+          a_mask[j] = mk;                                                                                   \
+        }                                                                                                   \
+      }                                                                                                     \
+    }                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                                        \
+      const int n = n0 + lrow + RPP * j;                                                                    \
+      b_voff[j] = n < p.Cout ? (unsigned)n * p.K * 2u + lchunk * 16u : INVALID;                             \
+    }                                                                                                       \
   }
   const unsigned a_bytes = (unsigned)p.N * p.H * p.W * p.Cin * 2u + bias;
   const unsigned b_bytes = (unsigned)p.Cout * p.K * 2u;
@@ -513,10 +535,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   }
 
   f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Pipeline (one barrier per k-tile, in the middle of it):
   //   phase A(kt): MFMAs of k-step 0 of tile kt; under them the fragment reads of k-step 1 (row i's A fragment is
@@ -525,66 +543,91 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   //   phase B(kt): MFMAs of k-step 1; under them the DMA of tile kt+2 into tile kt's buffer and the fragment
   //                reads of k-step 0 of tile kt+1
   // so neither the fragment reads nor the DMA issue ever run with the matrix pipe idle.
-  {
-    MDM_TILE_STATE(0);
-#pragma unroll
-    for (int q = 0; q < AJ + BJ; ++q) { MDM_DMA_PIECE(smem, q); }
+  // Across output tiles: the first two k-tiles of the NEXT output tile are requested from inside the epilogue, as
+  // soon as the staged tile has left the LDS, so they land while this tile's stores drain.
+#define MDM_TILE_PROLOGUE()                                                                                 \
+  {                                                                                                         \
+    MDM_TILE_STATE(0);                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < AJ + BJ; ++q) { MDM_DMA_PIECE(smem, q); }                         \
+  }                                                                                                         \
+  {                                                                                                         \
+    MDM_TILE_STATE(1);                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < AJ + BJ; ++q) { MDM_DMA_PIECE(smem + STAGE, q); }                 \
   }
-  {
-    MDM_TILE_STATE(1);
+
+  int tile = b_in_group;
+  if (tile >= tiles_total) return;
+  MDM_TILE_SETUP(tile);
+  MDM_TILE_PROLOGUE();
+  for (;;) {
 #pragma unroll
-    for (int q = 0; q < AJ + BJ; ++q) { MDM_DMA_PIECE(smem + STAGE, q); }
-  }
-  __syncthreads();
-  Frag<T> af[MT], b0[NT], b1[NT];
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-  for (int j = 0; j < NT; ++j) load_frag<T>(b0[j], smem + A_BYTES, wn * TN + j * 16 + l16, 0, quad);
-#pragma unroll
-  for (int i = 0; i < MT; ++i) load_frag<T>(af[i], smem, wm * TM + i * 16 + l16, 0, quad);
-  constexpr int DMA_PER_ROW = (AJ + BJ + MT - 1) / MT;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const char* As = smem + (kt & 1) * STAGE;
-    const char* Bs = As + A_BYTES;
-    // ---- phase A
-#pragma unroll
-    for (int j = 0; j < NT; ++j) load_frag<T>(b1[j], Bs, wn * TN + j * 16 + l16, 1, quad);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) mma16(acc[i][j], b0[j], af[i]);
-      load_frag<T>(af[i], As, wm * TM + i * 16 + l16, 1, quad);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-    sched_rows<NT, 0>(std::make_integer_sequence<int, MT>{});
-    __builtin_amdgcn_sched_barrier(0);
-    // hipcc does not count the loop-carried LDS-DMA of the previous phase B at this barrier: retire it explicitly
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's first k-tiles (and the previous tile's stores)
     __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- phase B
-    const char* An = smem + ((kt + 1) & 1) * STAGE;
-    const char* Bn = An + A_BYTES;
-    char* dst = smem + (kt & 1) * STAGE;
-    MDM_TILE_STATE(kt + 2);
+    Frag<T> af[MT], b0[NT], b1[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) load_frag<T>(b0[j], Bn, wn * TN + j * 16 + l16, 0, quad);
+    for (int j = 0; j < NT; ++j) load_frag<T>(b0[j], smem + A_BYTES, wn * TN + j * 16 + l16, 0, quad);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i) load_frag<T>(af[i], smem, wm * TM + i * 16 + l16, 0, quad);
+    constexpr int DMA_PER_ROW = (AJ + BJ + MT - 1) / MT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const char* As = smem + (kt & 1) * STAGE;
+      const char* Bs = As + A_BYTES;
+      // ---- phase A
 #pragma unroll
-      for (int j = 0; j < NT; ++j) mma16(acc[i][j], b1[j], af[i]);
+      for (int j = 0; j < NT; ++j) load_frag<T>(b1[j], Bs, wn * TN + j * 16 + l16, 1, quad);
 #pragma unroll
-      for (int d = 0; d < DMA_PER_ROW; ++d) { MDM_DMA_PIECE(dst, i * DMA_PER_ROW + d); }
-      load_frag<T>(af[i], An, wm * TM + i * 16 + l16, 0, quad);
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma16(acc[i][j], b0[j], af[i]);
+        load_frag<T>(af[i], As, wm * TM + i * 16 + l16, 1, quad);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+      sched_rows<NT, 0>(std::make_integer_sequence<int, MT>{});
+      __builtin_amdgcn_sched_barrier(0);
+      // hipcc does not count the loop-carried LDS-DMA of the previous phase B at this barrier: retire it explicitly
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase B
+      const char* An = smem + ((kt + 1) & 1) * STAGE;
+      const char* Bn = An + A_BYTES;
+      char* dst = smem + (kt & 1) * STAGE;
+      MDM_TILE_STATE(kt + 2);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) load_frag<T>(b0[j], Bn, wn * TN + j * 16 + l16, 0, quad);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma16(acc[i][j], b1[j], af[i]);
+#pragma unroll
+        for (int d = 0; d < DMA_PER_ROW; ++d) { MDM_DMA_PIECE(dst, i * DMA_PER_ROW + d); }
+        load_frag<T>(af[i], An, wm * TM + i * 16 + l16, 0, quad);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+      sched_rows<NT, DMA_PER_ROW>(std::make_integer_sequence<int, MT>{});
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-    sched_rows<NT, DMA_PER_ROW>(std::make_integer_sequence<int, MT>{});
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (empty) LDS-DMA issued past the last k-tile
+    __syncthreads();   // LDS is reused by the epilogue
+    const int cur_m0 = m0, cur_n0 = n0;
+    const int next = tile + G;
+    conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE>(p, acc, smem, cur_m0, cur_n0, [&]() {
+      if (next < tiles_total) {
+        MDM_TILE_SETUP(next);
+        MDM_TILE_PROLOGUE();
+      }
+    });
+    if (next >= tiles_total) break;
+    tile = next;
   }
-  __syncthreads();   // LDS is reused by the epilogue
+#undef MDM_TILE_PROLOGUE
+#undef MDM_TILE_SETUP
 #undef MDM_DMA_PIECE
 #undef MDM_TILE_STATE
 #undef MDM_BLDS
-  conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE>(p, acc, smem, m0, n0);
 #endif
 }
 
@@ -1598,6 +1641,17 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
   MDM_LAUNCH_STATUS();
 }
 
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+            ? pr.multiProcessorCount : 256;
+  }
+  return n;
+}
+
 template <int BM, int BN, int WM, int WN, int MODE>
 static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
@@ -1608,7 +1662,10 @@ static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), smem, st, a);
+  static int persist = -1;
+  if (persist < 0) { const char* e = getenv("MDM_HIP_PERSIST"); persist = e ? atoi(e) : 1; }   // 0: one block per tile (A/B testing)
+  const int resident = persist ? num_cus() * (WM * WN == 4 ? 2 : 1) : tiles;   // persistent blocks: one (8 waves) or two (4 waves) per CU
+  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a);
   MDM_NOTE_KERNEL("conv_gemm_bl_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, MODE);
   MDM_LAUNCH_STATUS();
 }
