@@ -82,15 +82,17 @@ int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulat
  * (unet.py:224, 233, 259, 268, 878) and nn.LayerNorm on the text states (unet.py:263, 304).
  *   y = act(GN(x; gamma, beta) * (1 + film[:, :C]) + film[:, C:]),  act: 0 none, 1 SiLU
  *   stats [N][G][2] = (mean, rstd), coef [N][C][2]: saved by forward, consumed by backward.
- *   mdm_gn_bwd writes dx, dgamma[C], dbeta[C] and dfilm [N][2C] (when film != NULL).
+ *   mdm_gn_bwd writes dx, dgamma[C], dbeta[C] and dfilm [N][2C] (when film != NULL).  dres (same shape as x, may be
+ *   NULL) is added into dx: the gradient that reaches x through the residual branch of the block the norm opens
+ *   (h = x + f(norm(x)), unet.py:238, 309, 312) -- saves the separate accumulation kernel of the autograd engine.
  *   ws (fp32) size from mdm_gn_plan (valid for both directions).
  */
 int mdm_gn_plan(int N, int HW, int C, int G, size_t* ws_bytes);
 int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, const void* film, void* y, float* stats,
                float* coef, float* ws, int N, int HW, int C, int G, float eps, int act, int dtype, void* stream);
 int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* film,
-               const float* stats, const float* coef, void* dx, float* dgamma, float* dbeta, void* dfilm, float* ws,
-               int N, int HW, int C, int G, int act, int accumulate, int dtype, void* stream);
+               const float* stats, const float* coef, const void* dres, void* dx, float* dgamma, float* dbeta,
+               void* dfilm, float* ws, int N, int HW, int C, int G, int act, int accumulate, int dtype, void* stream);
 int mdm_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int R, int D, float eps,
                int dtype, void* stream);
 /* ws: fp32 [ceil(R/64)][D][2] */

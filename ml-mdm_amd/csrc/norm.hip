@@ -273,8 +273,9 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restri
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ coef,
-                                                           const float* __restrict__ qr, T* __restrict__ dx, int HW,
-                                                           int C, int G, size_t total_chunks) {
+                                                           const float* __restrict__ qr, T* __restrict__ dx,
+                                                           const T* __restrict__ dres, int HW, int C, int G,
+                                                           size_t total_chunks) {
   constexpr int EPV = Tr<T>::EPV;
   const int cchunks = C / EPV;
   const int cpg = C / G;
@@ -297,6 +298,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
       float dz = cd.v[e];
       if (ACT) dz *= dsilu_f(ab[2 * e] * cx.v[e] + ab[2 * e + 1]);
       cd.v[e] = ab[2 * e] * dz + q * cx.v[e] + r;
+    }
+    if (dres) {
+      Chunk<T> cr;
+      cr.load(dres + i * EPV);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) cd.v[e] += cr.v[e];
     }
     cd.store(dx + i * EPV);
   }
@@ -432,8 +439,8 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const T* __restrict__ film, const float* __restrict__ stats,
                                                             const float* __restrict__ coef, T* __restrict__ dx,
-                                                            T* __restrict__ dfilm, float* __restrict__ pgrad, int HW,
-                                                            int C, int G, int CB) {
+                                                            T* __restrict__ dfilm, float* __restrict__ pgrad,
+                                                            const T* __restrict__ dres, int HW, int C, int G, int CB) {
   constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = NTHR / LPR, NW = NTHR / 64;
   __shared__ float sh[NW][LPR][2 * EPV];
   __shared__ float tot[LPR][2 * EPV];
@@ -530,6 +537,12 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
         float dz = vd.v[e];
         if (ACT) dz *= dsilu_f(a[e] * vx.v[e] + b[e]);
         vd.v[e] = a[e] * dz + qq * vx.v[e] + rr;
+      }
+      if (dres) {   // gradient that reaches x through the residual branch: added here instead of by a separate kernel
+        Chunk<T> vr;
+        vr.load(dres + base + (size_t)p * C);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) vd.v[e] += vr.v[e];
       }
       vd.store(dx + base + (size_t)p * C);
     }
@@ -692,8 +705,9 @@ extern "C" int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, 
 }
 
 extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* film,
-                          const float* stats, const float* coef, void* dx, float* dgamma, float* dbeta, void* dfilm,
-                          float* ws, int N, int HW, int C, int G, int act, int accumulate, int dtype, void* stream) {
+                          const float* stats, const float* coef, const void* dres, void* dx, float* dgamma,
+                          float* dbeta, void* dfilm, float* ws, int N, int HW, int C, int G, int act, int accumulate,
+                          int dtype, void* stream) {
   MDM_CHECK_ARG(dy && x && gamma && beta && stats && coef && dx && dgamma && dbeta && ws);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
   MDM_CHECK_ARG((film == nullptr) == (dfilm == nullptr));
@@ -711,8 +725,8 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
     const int lpr = dtype == DT_F32 ? 16 : 8;
     const int nthr = HW <= 4 * (512 / lpr) ? 512 : 1024;
 #define MDM_GN_FUSED_BWD(TT, ACT)                                                                                  \
-    if (nthr == 512) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 512>), grid, dim3(512), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, pgrad, HW, C, G, cb); \
-    else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 1024>), grid, dim3(1024), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, pgrad, HW, C, G, cb)
+    if (nthr == 512) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 512>), grid, dim3(512), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, pgrad, (const TT*)dres, HW, C, G, cb); \
+    else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 1024>), grid, dim3(1024), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, pgrad, (const TT*)dres, HW, C, G, cb)
     if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_BWD(float, 1); } else { MDM_GN_FUSED_BWD(float, 0); } }
     else { if (act) { MDM_GN_FUSED_BWD(bf16, 1); } else { MDM_GN_FUSED_BWD(bf16, 0); } }
 #undef MDM_GN_FUSED_BWD
@@ -729,7 +743,7 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
   hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pgrad, dgamma, dbeta, N, C,        \
                      accumulate);                                                                                    \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, ACT>), dim3(ab), dim3(256), 0, st, (const TT*)dy, (const TT*)x, coef, \
-                     qr, (TT*)dx, HW, C, G, total_chunks);
+                     qr, (TT*)dx, (const TT*)dres, HW, C, G, total_chunks);
   if (dtype == DT_F32) { if (act) { MDM_GN_BWD(float, 1) } else { MDM_GN_BWD(float, 0) } }
   else { if (act) { MDM_GN_BWD(bf16, 1) } else { MDM_GN_BWD(bf16, 0) } }
 #undef MDM_GN_BWD

@@ -467,7 +467,7 @@ class GroupNormFn(torch.autograd.Function):
     """y = act(GroupNorm(x) * (1 + film[:, :C]) + film[:, C:]);  act in {0: none, 1: SiLU}."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, film, groups, eps, act):
+    def forward(ctx, x, gamma, beta, film, groups, eps, act, passthrough):
         _require_gpu(x)
         x, film = _c(x), _c(film)
         N, C = x.shape[0], x.shape[-1]
@@ -484,12 +484,18 @@ class GroupNormFn(torch.autograd.Function):
         )
         ctx.save_for_backward(x, gamma, beta, film, stats, coef)
         ctx.groups, ctx.act = groups, act
+        ctx.passthrough = passthrough
+        if passthrough:
+            # second output = x itself: the caller routes the block's residual branch through it, so the gradient of
+            # that branch arrives HERE (dres) and is added inside the GroupNorm backward kernel
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, beta, film, stats, coef = ctx.saved_tensors
         dy = _c(dy)
+        dres = _c(dres) if dres is not None else None
         N, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (N * C)
         g32, b32 = _c(gamma.detach().float()), _c(beta.detach().float())
@@ -501,19 +507,21 @@ class GroupNormFn(torch.autograd.Function):
         dfilm = torch.empty_like(film) if film is not None else None
         ws = _gn_ws(N, HW, C, ctx.groups, x.device)
         _lib.check(
-            _lib.lib().mdm_gn_bwd(_p(dy), _p(x), _p(g32), _p(b32), _p(film), _p(stats), _p(coef), _p(dx), _p(dgamma),
+            _lib.lib().mdm_gn_bwd(_p(dy), _p(x), _p(g32), _p(b32), _p(film), _p(stats), _p(coef), _p(dres), _p(dx), _p(dgamma),
                                   _p(dbeta), _p(dfilm), _p(ws), N, HW, C, ctx.groups, ctx.act, 1 if sunk else 0, _dt(x), _stream()),
             "mdm_gn_bwd",
         )
         if sunk:
             _grad_sink.ready(gamma)
             _grad_sink.ready(beta)
-            return dx, None, None, dfilm, None, None, None
-        return dx, dgamma, dbeta, dfilm, None, None, None
+            return dx, None, None, dfilm, None, None, None, None
+        return dx, dgamma, dbeta, dfilm, None, None, None, None
 
 
-def group_norm(x, gamma, beta, groups, eps=1e-5, film=None, silu=False):
-    return GroupNormFn.apply(x, gamma, beta, film, groups, eps, 1 if silu else 0)
+def group_norm(x, gamma, beta, groups, eps=1e-5, film=None, silu=False, passthrough=False):
+    """``passthrough=True`` returns ``(y, x_res)``: use ``x_res`` (== x) for the residual branch of the block this
+    norm opens, and the residual gradient is folded into the norm's backward kernel."""
+    return GroupNormFn.apply(x, gamma, beta, film, groups, eps, 1 if silu else 0, passthrough)
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -125,7 +125,7 @@ class ResNet(nn.Module):
         if self.config.dropout > 0 and self.training:
             raise NotImplementedError("dropout > 0 is not implemented on the HIP path")
         g = self.config.num_groups_norm
-        h = ops.group_norm(x, self.norm1.weight, self.norm1.bias, g, self.norm1.eps, silu=True)
+        h, x = ops.group_norm(x, self.norm1.weight, self.norm1.bias, g, self.norm1.eps, silu=True, passthrough=True)
         h = ops.conv(h, self.conv1.weight, self.conv1.bias)
         film = ops.linear(temb_act, self.time_layer.weight, self.time_layer.bias)
         if film.shape[0] != h.shape[0]:
@@ -167,7 +167,7 @@ class SelfAttention(nn.Module):
 
     def forward(self, x, cond=None, cond_mask=None):
         N, H, W, C = x.shape
-        hn = ops.group_norm(x, self.norm.weight, self.norm.bias, 32, self.norm.eps)
+        hn, x = ops.group_norm(x, self.norm.weight, self.norm.bias, 32, self.norm.eps, passthrough=True)
         qkv = ops.conv(hn, self.qkv.weight, self.qkv.bias)
         kvc = None
         if self.cond_dim is not None and self.cond_dim > 0:
@@ -176,7 +176,7 @@ class SelfAttention(nn.Module):
         a = ops.attention(qkv.reshape(N, H * W, 3 * C), kvc, cond_mask if kvc is not None else None, self.num_heads)
         x = ops.conv(a.reshape(N, H, W, C), self.proj_out.weight, self.proj_out.bias, residual=x)
         if self.ffn is not None:
-            fn = ops.group_norm(x, self.ffn[0].weight, self.ffn[0].bias, 32, self.ffn[0].eps)
+            fn, x = ops.group_norm(x, self.ffn[0].weight, self.ffn[0].bias, 32, self.ffn[0].eps, passthrough=True)
             x = ops.ffn(fn, self.ffn[1].weight, self.ffn[1].bias, self.ffn[3].weight, self.ffn[3].bias, residual=x)
         return x
 

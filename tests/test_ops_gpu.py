@@ -220,6 +220,33 @@ def test_group_norm(dtype, N, HW, C, G, film, silu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,HW,C,G", [(2, 256, 768, 32), (2, 1024, 64, 32), (2, 1024, 512, 32)])
+def test_group_norm_residual_passthrough(dtype, N, HW, C, G):
+    """h = x + f(norm(x)): the residual branch is routed through the norm's second output, so its gradient is added
+    inside the GroupNorm backward kernel (single-kernel and three-kernel paths)."""
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(5)
+    H = int(math.isqrt(HW)); W = HW // H
+    x = q(torch.randn(N, C, H, W, generator=g), dtype).requires_grad_()
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_()
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_()
+    w_res = q(torch.randn(N, C, H, W, generator=g), dtype)          # makes the two branch gradients different
+    y_ref = F.silu(F.group_norm(x, G, gamma, beta, 1e-5)) * 1.5 + x * w_res
+    gy = q(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+    xd = nhwc(x.detach(), dtype).requires_grad_()
+    gd, bd = gamma.detach().to(dev()).requires_grad_(), beta.detach().to(dev()).requires_grad_()
+    y, xr = ops.group_norm(xd, gd, bd, G, 1e-5, silu=True, passthrough=True)
+    out = y.float() * 1.5 + xr.float() * nhwc(w_res, dtype).float()
+    out.backward(nhwc(gy, dtype).float())
+    tol = TOL[dtype]
+    assert relerr(nchw(out), y_ref) < tol
+    assert relerr(nchw(xd.grad), x.grad) < tol
+    assert relerr(gd.grad, gamma.grad) < tol and relerr(bd.grad, beta.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_layer_norm(dtype):
     from mdm_hip import ops
 
