@@ -68,30 +68,16 @@ def synthetic_batch(batch, side, device, seed):
 
 
 def pmc_traffic(kernel_label):
-    """HBM bytes per launch of the named kernel from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, gfx950 FETCH_SIZE x2 correction).  The label
-    used by the live timing is mapped to the rocprof kernel name; None when there is no measurement for it."""
-    import re
-
+    """HBM bytes per launch of the named kernel from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json, built
+    by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, with the gfx950
+    FETCH_SIZE x2 correction).  ``kernel_label`` is the kernel name as rocprofv3 prints it (without arguments);
+    None when there is no measurement for it."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
     if not os.path.exists(path):
         return None
     table = json.load(open(path))["kernels"]
-    m = re.match(r"conv_wgrad_tr_kernel<bf16,(\d+)x\d+,(1x1|3x3)>", kernel_label)
-    if m:
-        want = "conv_wgrad_tr_kernel<%d, %d>" % (1 if m.group(2) == "3x3" else 0, 1 if m.group(1) == "256" else 0)
-    else:
-        m = re.match(r"conv_gemm_kernel<bf16,(\d+)x(\d+),(1x1|3x3|3x3_T2)>", kernel_label)
-        if not m:
-            return None
-        mode = {"1x1": 0, "3x3": 1, "3x3_T2": 2}[m.group(3)]
-        want = "conv_gemm_kernelIDF16bLi%sELi%sELi" % (m.group(1), m.group(2))
-        for k, v in table.items():
-            if want in k and re.search(r"Li%dELi[23]ELb" % mode, k):
-                return v["hbm_bytes_per_launch"]
-        return None
     for k, v in table.items():
-        if want in k:
+        if kernel_label in k:
             return v["hbm_bytes_per_launch"]
     return None
 
