@@ -210,7 +210,9 @@ def _prof_wrap(name, flops, fn):
 
 
 def profile_end(peak_tflops):
-    """-> the ``roofline`` object of bench.py for the kernel with the largest total time."""
+    """-> the ``roofline`` object of bench.py for the dominant kernel = the one that executes the most algorithmic
+    FLOPs of the step (the 3x3 forward / input-gradient GEMM; it is also first by total time in the rocprofv3
+    statistics, but only by a hair over the 1x1 kernel, so ranking by time flipped between runs)."""
     global _prof
     rec, _prof = _prof, None
     torch.cuda.synchronize()
@@ -224,7 +226,7 @@ def profile_end(peak_tflops):
         return None
     table = {k: {"launches": v[0], "alg_tflop": round(v[1] / 1e12, 3), "time_ms": round(v[2] * 1e3, 3),
                  "tflops": round(v[1] / v[2] / 1e12, 1)} for k, v in agg.items()}
-    dom = max(agg, key=lambda k: agg[k][2])
+    dom = max(agg, key=lambda k: agg[k][1])
     n, fl, t = agg[dom]
     ach = fl / t / 1e12
     return {
