@@ -188,14 +188,18 @@ def main():
         samp = {"ms_per_denoise_step": round(ms_it, 3), "batch_per_gpu": sb, "images_per_s_at_%d_steps" % demo_steps:
                 round(world * sb / (demo_steps * ms_it / 1e3), 3), "sampler": "DDIM eta=0, CFG off", "timed_steps": n_it}
     roof = None
-    if not args.no_roofline and rank == 0:
-        # one extra, untimed step with HIP events around every GEMM-class launch (on the launch stream)
-        ops.profile_begin()
+    if not args.no_roofline:
+        # one extra, untimed step with HIP events around every GEMM-class launch (on the launch stream).  Every rank
+        # runs the step (it contains the gradient all-reduce); only rank 0 records and reports.
+        pipe.train()
+        if rank == 0:
+            ops.profile_begin()
         step(sample)
         torch.cuda.synchronize()
-        roof = ops.profile_end(PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS)
-        if roof is not None and args.workload == "unet64" and args.dtype == "bf16" and batch == 64:
-            roof["traffic"] = pmc_traffic(roof["kernel"])   # HBM bytes per launch (PMC), null if not collected
+        if rank == 0:
+            roof = ops.profile_end(PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS)
+            if roof is not None and args.workload == "unet64" and args.dtype == "bf16" and batch == 64:
+                roof["traffic"] = pmc_traffic(roof["kernel"])   # HBM bytes per launch (PMC), null if not collected
     if world > 1:
         dist.barrier()
 
