@@ -66,6 +66,9 @@ def nchw(t_nhwc):
         (5, 9, 7, 64, 136, 1, 1),       # 128x128, 1x1, M = 315
         (2, 16, 16, 256, 320, 3, 1),    # 256x256 tile (K = 2304), ragged Cout
         (4, 128, 128, 64, 264, 1, 1),   # 256x256, 1x1 (M = 65536), K below one tile
+        # 1024 tiles of 128x128 on 512 resident blocks: the persistent kernel's second output tile per block
+        (8, 128, 128, 64, 128, 1, 1),   # single k-tile (K = 64)
+        (8, 128, 128, 64, 128, 3, 1),
     ],
 )
 def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
