@@ -133,13 +133,19 @@ def test_conv_padded_stem_and_head(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_linear_small_rows(dtype):
+@pytest.mark.parametrize("M,K,N", [
+    (5, 128, 72),          # tiled GEMM (N not a multiple of 16)
+    (64, 1024, 1536),      # time_layer shape (with MDM_HIP_SMALLM=1: the experimental split-K small-M kernel)
+    (33, 256, 1024),       # ragged rows
+    (7, 2048, 48),         # K > one round of the four waves
+])
+def test_linear_small_rows(dtype, M, K, N):
     from mdm_hip import ops
 
     g = torch.Generator().manual_seed(2)
-    x = q(torch.randn(5, 128, generator=g), dtype).requires_grad_()
-    w = q(torch.randn(72, 128, generator=g) / 11, dtype).requires_grad_()
-    b = torch.randn(72, generator=g).requires_grad_()
+    x = q(torch.randn(M, K, generator=g), dtype).requires_grad_()
+    w = q(torch.randn(N, K, generator=g) / math.sqrt(K), dtype).requires_grad_()
+    b = torch.randn(N, generator=g).requires_grad_()
     y_ref = F.linear(x, w, b)
     gy = q(torch.randn(y_ref.shape, generator=g), dtype)
     y_ref.backward(gy)
