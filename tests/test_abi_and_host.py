@@ -37,6 +37,38 @@ def test_plan_functions_are_host_only():
     assert b"splits_out" in L.mdm_last_error()
 
 
+def test_tile_and_split_cost_models():
+    """host-side launch planning (no GPU): GEMM tile choice and wgrad tile / split count"""
+    from mdm_hip import _lib
+
+    L = _lib.lib()
+    BF16, F32 = 1, 0
+    # forward / dgrad tile = BM * 1000 + BN
+    assert L.mdm_conv_fwd_tile(16384, 768, BF16) == 256192      # N = 768 at M = 16384: exactly one round of 256x192 tiles
+    assert L.mdm_conv_fwd_tile(16384, 2304, BF16) == 256192
+    assert L.mdm_conv_fwd_tile(262144, 256, BF16) == 256256     # 1024 tiles = 4 whole rounds
+    assert L.mdm_conv_fwd_tile(65536, 512, BF16) == 256256
+    assert L.mdm_conv_fwd_tile(2048, 1536, BF16) == 128128      # too few rows for a round of the large tiles
+    assert L.mdm_conv_fwd_tile(4096, 8, BF16) == 128032 and L.mdm_conv_fwd_tile(4096, 64, BF16) == 128064
+    assert L.mdm_conv_fwd_tile(16384, 768, F32) == 128128       # fp32 (parity mode): one tile shape
+    # wgrad: blocks = tiles x splits must not spill a nearly empty extra round over the resident blocks
+    for (M, Cout, K) in [(16384, 768, 3072), (16384, 3072, 768), (65536, 512, 4608), (262144, 256, 2304), (65536, 2048, 512)]:
+        sp, ws = ctypes.c_int(0), ctypes.c_size_t(0)
+        assert L.mdm_conv_wgrad_plan(M, Cout, K, BF16, ctypes.byref(sp), ctypes.byref(ws)) == 0
+        te = L.mdm_conv_wgrad_tile(M, Cout, K, BF16)
+        assert te in (128, 256) and 1 <= sp.value <= 64
+        tiles = -(-Cout // te) * -(-K // te)
+        slots = 256 if te == 256 else 512
+        blocks = tiles * sp.value
+        rounds = -(-blocks // slots)
+        assert blocks >= 0.8 * rounds * slots, (M, Cout, K, te, sp.value, blocks)
+        mt = -(-M // 64)
+        per = -(-mt // sp.value)
+        assert -(-mt // per) == sp.value                        # canonical: no empty split
+    assert L.mdm_conv_wgrad_tile(4096, 64, 64, BF16) == 128     # 256 needs both output dims >= 192
+    assert L.mdm_conv_wgrad_tile(16384, 768, 3072, F32) == 128
+
+
 def test_invalid_arguments_rejected_before_launch():
     from mdm_hip import _lib
 
