@@ -1838,8 +1838,8 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static int smallm = -1;
   // EXPERIMENT, off by default: numerically verified (tests/test_ops_gpu.py::test_linear_small_rows with
-  // MDM_HIP_SMALLM=1) but the one step-level A/B of the round came out slower (124.8 vs 106.1 ms/step) and the GPU
-  // budget ended before the cause could be found -- do not enable without re-measuring.
+  // MDM_HIP_SMALLM=1), but its only step-level A/B (124.8 vs 106.1 ms/step, run first on a box on which everything
+  // was slow that day) was inconclusive and the GPU budget ended there -- re-measure before enabling.
   if (smallm < 0) { const char* e = getenv("MDM_HIP_SMALLM"); smallm = e ? atoi(e) : 0; }
   if (smallm && dtype == DT_BF16 && ksize == 1 && a.M <= 64 && act == 0 && !res && !aux && !y_pre && a.K % 32 == 0 &&
       Cout % 16 == 0 && !dbg) {
