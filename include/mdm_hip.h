@@ -34,9 +34,6 @@ enum { MDM_ACT_NONE = 0, MDM_ACT_GELU = 1, MDM_ACT_DGELU_AUX = 2 };
 
 int mdm_abi_version(void);
 const char* mdm_last_error(void);
-/* Name (as a profiler prints it, without arguments) of the GEMM-class kernel the calling thread launched last;
- * bench.py uses it to label per-launch HIP-event timings.  Development aid, not part of the reference surface. */
-const char* mdm_last_gemm_kernel(void);
 
 /* ---- convolution / linear (implicit GEMM on MFMA) --------------------------------------
  * replaces nn.Conv2d 3x3 s1/s2 p1 and 1x1 (models/unet.py:199-221, 260-271, 514-532, 632, 751;
@@ -66,9 +63,6 @@ int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, i
 int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const void* res, const void* aux, void* y,
                  void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride,
                  int transposed, int act, int kblock, int dtype, void* stream);
-/* host-only: block tile (BM * 1000 + BN) mdm_conv_fwd will use for (M, Cout, dtype) -- for profiling labels */
-int mdm_conv_fwd_tile(int M, int Cout, int dtype);
-int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype);   /* 128 or 256 (square output tile edge) */
 int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes);
 int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, float* ws, int N, int H, int W, int Cin, int Ho,
                    int Wo, int Cout, int ksize, int stride, int dtype, void* stream);
@@ -82,7 +76,8 @@ int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulat
  * (unet.py:224, 233, 259, 268, 878) and nn.LayerNorm on the text states (unet.py:263, 304).
  *   y = act(GN(x; gamma, beta) * (1 + film[:, :C]) + film[:, C:]),  act: 0 none, 1 SiLU
  *   stats [N][G][2] = (mean, rstd), coef [N][C][2]: saved by forward, consumed by backward.
- *   mdm_gn_bwd writes dx, dgamma[C], dbeta[C] and dfilm [N][2C] (when film != NULL).  dres (same shape as x, may be
+ *   mdm_gn_bwd writes dx, dgamma[C], dbeta[C] (fp32 atomic accumulation of one term per sample: `accumulate` == 0
+ *   zero-fills them first) and dfilm [N][2C] (when film != NULL).  dres (same shape as x, may be
  *   NULL) is added into dx: the gradient that reaches x through the residual branch of the block the norm opens
  *   (h = x + f(norm(x)), unet.py:238, 309, 312) -- saves the separate accumulation kernel of the autograd engine.
  *   ws (fp32) size from mdm_gn_plan (valid for both directions).
@@ -146,6 +141,54 @@ int mdm_sumsq(const float* g, float* out, float* ws, size_t n, void* stream);
 int mdm_adamw_ema_step(float* p, float* g, float* m, float* v, float* ema, const float* gnorm_sq, size_t n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, int step, float clip, float ema_decay,
                        int zero_grad, void* stream);
+
+/* ---- per-pixel arithmetic around the denoiser (NCHW fp32 images, as the reference keeps them) ---------------
+ * All [B, chw] images need chw % 4 == 0.  gamma / gamma_last are per-sample device vectors [B].
+ * `rng_state` is a device pointer to {uint64 seed, uint64 offset}: Philox4x32-10 + Box-Muller, element i = lane
+ * i & 3 of counter block offset + i / 4 of stream `rng_stream` -- reproducible on the host (oracle/philox_ref.py).
+ * mdm_rng_advance bumps the offset on the device (graph-capturable); mdm_randn fills n (% 4 == 0) normals.
+ *
+ * mdm_sampler_step: one reverse-diffusion update, replaces Sampler.get_prediction_xt_last +
+ *   clip_sample + the guidance combine of forward_model (samplers.py:281-345, 445-456, 500-508):
+ *     p = pred_uncond ? pred_uncond + guidance * (pred - pred_uncond) : pred
+ *     x0 = (pred_type == 2 (V)) ? x_t sqrt(g) - p sqrt(1-g) : (x_t - p sqrt(1-g)) / sqrt(g)
+ *     clip 0: none; 1: clamp(x0 s, -1, 1) / s; 2: clamp(x0 s, -thr[b], thr[b]) / thr[b] / s (dynamic thresholding, thr
+ *       = the clamped quantile of |x0 s|, computed by the caller); 3: write the UNCLIPPED x0 s to x0_out and stop
+ *     mode 0 (ddim_eta None): x_last = x0 beta sqrt(gl) / (1-g) + x_t sqrt(alpha) (1-gl) / (1-g)
+ *     mode 1: eps = (x_t - x0 sqrt(g)) / sqrt(1-g); x_last = x0 sqrt(gl) + eps sqrt(1 - gl - eta^2 beta~) (eta = 0: no noise)
+ *     need_noise: x_last += sqrt(beta~) * noise_gate[0] * n, n = noise[] if given, else drawn from rng_state
+ * mdm_noise_images (N3, samplers.py:244-246): x_t = sqrt(g) images inv_scale + sqrt(1-g) eps; eps == NULL draws it
+ *   from rng_state and stores it to eps_out.
+ * mdm_diffusion_loss_fwd / _bwd (N3, diffusion.py:144-168 + samplers.py:266-279, 347-390): loss[b] = mean over chw of
+ *   (prediction mapped to the loss-target space - target)^2 for prediction / target types 0,1 (eps) or 2 (v);
+ *   dpred = gloss[b] * d loss[b] / d pred.  ws from mdm_diffusion_loss_plan.
+ * mdm_avgpool: F.avg_pool2d(x, r) of the image pyramid (diffusion.py:346-348).
+ * mdm_sample_std_fwd / _bwd: y = x / std(x over chw, unbiased) per sample (models/unet.py:871-872, the nested level
+ *   with skip_normalization = false); stats [N][2] = (mean, 1 / std); ws = fp32 [N][64][2].
+ * mdm_input_stage (N4, clis/train_parallel.py:194-195): uint8 NHWC [B,H,W,3] -> fp32 NCHW, (u - 127) / 128.
+ */
+int mdm_rng_advance(unsigned long long* rng_state, unsigned long long blocks, void* stream);
+int mdm_randn(float* out, size_t n, const unsigned long long* rng_state, int rng_stream, void* stream);
+int mdm_sampler_step(const float* x_t, const float* pred, const float* pred_uncond, float guidance, const float* gamma,
+                     const float* gamma_last, const float* noise, const float* noise_gate, const float* thr,
+                     const unsigned long long* rng_state, int rng_stream, float* x0_out, float* x_last_out, int B,
+                     size_t chw, int pred_type, int mode, float ddim_eta, int need_noise, int clip, float image_scale,
+                     void* stream);
+int mdm_noise_images(const float* images, const float* eps, const float* gamma, float inv_scale, float* x_t,
+                     float* eps_out, const unsigned long long* rng_state, int rng_stream, int B, size_t chw,
+                     void* stream);
+int mdm_diffusion_loss_plan(int B, size_t chw, size_t* ws_bytes);
+int mdm_diffusion_loss_fwd(const float* x_t, const float* pred, const float* images, const float* eps,
+                           const float* gamma, float inv_scale, float* loss, float* ws, int B, size_t chw,
+                           int pred_type, int target_type, void* stream);
+int mdm_diffusion_loss_bwd(const float* x_t, const float* pred, const float* images, const float* eps,
+                           const float* gamma, const float* gloss, float inv_scale, float* dpred, int B, size_t chw,
+                           int pred_type, int target_type, void* stream);
+int mdm_avgpool(const float* x, float* y, int N, int C, int H, int W, int r, void* stream);
+int mdm_sample_std_fwd(const float* x, float* y, float* stats, float* ws, int N, size_t chw, void* stream);
+int mdm_sample_std_bwd(const float* dy, const float* x, const float* stats, float* dx, float* ws, int N, size_t chw,
+                       void* stream);
+int mdm_input_stage(const void* u8_nhwc, float* out_nchw, int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -788,33 +788,16 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
 
 using namespace mdm;
 
-template <typename K>
-static void set_smem(K kern, int bytes) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
-
 template <typename T, int D>
 static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   using G = AttnGeom<T, D>;
   constexpr int smem = sizeof(T) == 2 ? 4 * G::NAT_BYTES : G::NAT_BYTES + (G::NAT_BYTES > G::TR_BYTES ? G::NAT_BYTES : G::TR_BYTES);
-  static int qt_env = -1;
-  if (qt_env < 0) { const char* e = getenv("MDM_HIP_ATTN_QT"); qt_env = e ? atoi(e) : 2; }   // queries per wave / 16 (A/B testing)
-  static bool done = false;
-  if (!done) {
-    set_smem(attn_fwd_kernel<T, D, 2, true>, smem); set_smem(attn_fwd_kernel<T, D, 2, false>, smem);
-    set_smem(attn_fwd_kernel<T, D, 1, true>, smem); set_smem(attn_fwd_kernel<T, D, 1, false>, smem);
-    done = true;
-  }
+  ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, true>, smem);
+  ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, false>, smem);
   const bool ocm = !a.kc || a.out_cross;   // nothing to keep, or a buffer to keep it in
-  if (qt_env == 1) {
-    dim3 grid((a.L + 63) / 64, a.B * a.H);
-    if (ocm) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, true>), grid, dim3(256), smem, st, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, false>), grid, dim3(256), smem, st, a);
-  } else {
-    dim3 grid((a.L + 127) / 128, a.B * a.H);
-    if (ocm) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, true>), grid, dim3(256), smem, st, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, false>), grid, dim3(256), smem, st, a);
-  }
+  dim3 grid((a.L + 127) / 128, a.B * a.H);   // 32 queries per wave: every K / V fragment feeds two MFMAs
+  if (ocm) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, true>), grid, dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, false>), grid, dim3(256), smem, st, a);
   MDM_LAUNCH_STATUS();
 }
 
@@ -823,24 +806,15 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
   using G = AttnGeom<T, D>;
   constexpr int smem_q = sizeof(T) == 2 ? 4 * G::NAT_BYTES : 2 * G::NAT_BYTES + G::TR_BYTES;
   constexpr int smem_kv = sizeof(T) == 2 ? 2 * (2 * G::NAT_BYTES + 512) : 2 * G::NAT_BYTES + 2 * G::TR_BYTES + 512;
-  auto kkv = attn_bwd_dkv_kernel<T, D, 1>;
-  constexpr int KTS = 1;   // 2 key tiles per wave measured SLOWER (286-331 registers -> 1 wave / SIMD): 2.18 vs 1.59 ms
-  auto kkv2 = attn_bwd_dkv_kernel<T, D, KTS>;
+  auto kkv = attn_bwd_dkv_kernel<T, D, 1>;   // 2 key tiles per wave measured SLOWER (286-331 registers -> 1 wave / SIMD)
   // queries per wave of the dQ kernel: 32 (QT = 2) reuses each K / V fragment twice; at d = 96 its two operand sets
   // (Q, dO) + two score tiles no longer fit 256 registers, so 16 (QT = 1, three waves per SIMD) wins there
-  static int qt_env = -1;
-  if (qt_env < 0) { const char* e = getenv("MDM_HIP_ATTN_DQ_QT"); qt_env = e ? atoi(e) : (D >= 96 ? 1 : 2); }
-  static bool done = false;
-  if (!done) {
-    set_smem(attn_bwd_dq_kernel<T, D, 1>, smem_q); set_smem(attn_bwd_dq_kernel<T, D, 2>, smem_q);
-    set_smem(kkv, smem_kv); set_smem(kkv2, smem_kv);
-    done = true;
-  }
-  if (qt_env == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 1>), dim3((a.L + 63) / 64, a.B * a.H), dim3(256), smem_q, st, a);
-  else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 2>), dim3((a.L + 127) / 128, a.B * a.H), dim3(256), smem_q, st, a);
+  constexpr int DQ_QT = D >= 96 ? 1 : 2;
+  ensure_dynamic_lds(attn_bwd_dq_kernel<T, D, DQ_QT>, smem_q);
+  ensure_dynamic_lds(kkv, smem_kv);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, DQ_QT>), dim3((a.L + 64 * DQ_QT - 1) / (64 * DQ_QT), a.B * a.H), dim3(256), smem_q, st, a);
   a.pass = 0;
-  if (a.L >= 128) hipLaunchKernelGGL(kkv2, dim3((a.L + 64 * KTS - 1) / (64 * KTS), a.B * a.H), dim3(256), smem_kv, st, a);
-  else hipLaunchKernelGGL(kkv, dim3((a.L + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);
+  hipLaunchKernelGGL(kkv, dim3((a.L + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);
   if (a.kc) {
     a.pass = 1; a.dk = dkc; a.dv = dvc; a.dk_bs = dc_bs; a.dk_rs = dc_rs;
     hipLaunchKernelGGL(kkv, dim3((a.S + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);

@@ -10,6 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <unordered_set>
+
 namespace mdm {
 
 typedef __bf16 bf16;
@@ -237,3 +240,37 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   } while (0)
 
 extern "C" void mdm_set_error(const char* file, int line, const char* what);
+
+// ---- host-side per-device state ----------------------------------------------------------------------------------
+// Kernel attributes (dynamic LDS above 64 KB) and the CU count belong to a DEVICE, and a process may touch several
+// (tests on cuda:1, a single-process multi-GPU host): both are keyed by hipGetDevice(), and the table is guarded
+// because forward (caller thread) and backward (autograd thread) launch concurrently.
+namespace mdm {
+inline int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d;
+}
+template <typename K>
+inline void ensure_dynamic_lds(K kern, int bytes) {
+  static std::mutex mu;
+  static std::unordered_set<uint64_t> done;
+  const uint64_t key = (uint64_t)reinterpret_cast<uintptr_t>(reinterpret_cast<const void*>(kern)) ^
+                       ((uint64_t)(unsigned)current_device() << 56) ^ ((uint64_t)(unsigned)bytes << 40);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count(key)) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.insert(key);
+}
+inline int device_cus() {
+  static std::mutex mu;
+  static int cus[64] = {};
+  const int d = current_device() & 63;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cus[d]) {
+    hipDeviceProp_t pr;
+    cus[d] = (hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  return cus[d];
+}
+}  // namespace mdm

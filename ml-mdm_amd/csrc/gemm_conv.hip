@@ -42,7 +42,6 @@ struct ConvArgs {
   int act;            // 0 none, 1 y=gelu(v), 2 y=v*gelu'(aux)
   int kblk;           // 3x3 k-order: 0 = tap-major (k = tap*Cin + cin); B = channel-block-major,
                       // k = (cin / B) * 9 * B + tap * B + cin % B with B = the k-tile (64 bf16 / 32 fp32)
-  int dbg;            // development ablations (MDM_HIP_GEMM_DBG): 1 = no DMA after tile 0, 2 = no MFMA phase; 0 in production
 };
 
 enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };
@@ -80,7 +79,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
   // bias / activation / residual are applied in registers (fp32); the finished tile is then staged through
   // LDS (free after the k-loop) so that HBM sees whole 16-byte chunks of complete output rows instead of the
   // 8-byte-per-lane fragments of the MFMA layout (the output-heavy 1x1 convs -- qkv, FFN up -- were store-bound).
-  if (p.dbg & 8) { __syncthreads(); after_lds(); return; }
   T* __restrict__ Y = reinterpret_cast<T*>(p.y);
   T* __restrict__ Ypre = reinterpret_cast<T*>(p.ypre);
   const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
@@ -124,7 +122,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
     //    The activation sees the value already rounded to T -- what the reference's autocast graph does too
     //    (conv output in bf16, then GELU / add as separate bf16 ops); in fp32 mode nothing is rounded.
     const int act = p.act;
-    const bool skip_store = (p.dbg & 4) != 0;
     constexpr int NCH = BM * OCH / NT_;   // staged chunks per thread
     static_assert(NCH * NT_ == BM * OCH, "staged tile must divide evenly over the block");
     uint4 raw[NCH];
@@ -141,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
       const int idx = tid + i * NT_;
       const int row = idx / OCH, ch = idx - row * OCH;
       const int m = m0 + row, n = n0 + ch * EPV;
-      if (m >= p.M || n >= p.Cout || skip_store) continue;
+      if (m >= p.M || n >= p.Cout) continue;
       const size_t o = (size_t)m * p.Cout + n;
       if (act == 0 && !R) {
         *reinterpret_cast<uint4*>(Y + o) = raw[i];
@@ -200,16 +197,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
   }
 }
 
-// NSTAGE = 2: 4-wave block, next tile's DMA overlaps this tile's MFMAs, __syncthreads() drains it (vmcnt(0)).
-// NSTAGE = 3: 8-wave block (256-row tile), DMA runs TWO tiles ahead; a counted s_waitcnt vmcnt(loads per tile) +
-//             raw s_barrier retires only the tile needed next, so loads stay in flight across the barrier
-//             (cdna_hip_programming.md section 5, "Pipelining across barriers").
-// PP (ping-pong, 8-wave tiles only): the two waves that share a SIMD (w and w + 4) run one segment apart --
-//     while one issues its 32 MFMAs of a k-step the other does its LDS fragment reads / next-tile DMA -- with a
-//     raw s_barrier after every segment, so the matrix pipe always has exactly one wave feeding it instead of
-//     both waves loading together and then fighting for the pipe.
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int NSTAGE, bool PP = false>
+// Double-buffered: the next tile's LDS-DMA overlaps this tile's MFMAs; __syncthreads() drains it (vmcnt(0)).
+template <typename T, int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(ConvArgs p) {
+  constexpr int NSTAGE = 2;
   constexpr int EPV = Tr<T>::EPV, BK = Tr<T>::BK, KSTEPS = Tr<T>::KSTEPS;
   constexpr int NT_ = WM * WN * 64;                  // threads per block
   constexpr int RPP = NT_ / 8;                       // tile rows staged per pass (8 chunk lanes per row)
@@ -327,88 +318,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(ConvArgs p) 
         _Pragma("unroll") for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);                   \
     }                                                                                                     \
   }
-  if constexpr (NSTAGE == 2 && PP) {
-    static_assert(WM * WN == 8 && KSTEPS == 2, "ping-pong schedule: 8 waves, two k-steps per tile");
-    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
-    MDM_STAGE_TILE(smem);
-    __syncthreads();                                  // tile 0 landed
-    if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one segment behind group 0
-    for (int kt = 0; kt < ntiles; ++kt) {
-      const char* As = smem + (kt & 1) * STAGE;
-      const char* Bs = As + A_BYTES;
-      Frag<T> af[MT], bfr[NT];
-      // ---- segment L0: next tile's DMA + fragment reads of k-step 0
-      if (kt + 1 < ntiles) MDM_STAGE_TILE(smem + ((kt + 1) & 1) * STAGE);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) load_frag<T>(af[i], As, wm * TM + i * 16 + l16, 0, quad);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) load_frag<T>(bfr[j], Bs, wn * TN + j * 16 + l16, 0, quad);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- segment M0
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- segment L1: fragment reads of k-step 1
-#pragma unroll
-      for (int i = 0; i < MT; ++i) load_frag<T>(af[i], As, wm * TM + i * 16 + l16, 1, quad);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) load_frag<T>(bfr[j], Bs, wn * TN + j * 16 + l16, 1, quad);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // group 1's L1 is the segment right before group 0 reads the next tile: its DMA must have landed by now
-      if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- segment M1
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);
-      __builtin_amdgcn_s_setprio(0);
-      if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's extra leading barrier
-    __syncthreads();                                  // LDS is reused by the epilogue
-  } else if constexpr (NSTAGE == 2) {
-    MDM_STAGE_TILE(smem);
-    __syncthreads();
-    for (int kt = 0; kt < ntiles; ++kt) {
-      char* cur = smem + (kt & 1) * STAGE;
-      if (kt + 1 < ntiles && !(p.dbg & 1)) MDM_STAGE_TILE(smem + ((kt + 1) & 1) * STAGE);
-      if (!(p.dbg & 2)) MDM_COMPUTE_TILE(cur);
-      __syncthreads();   // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
-    }
-  } else {
-    // ring of 3 buffers, DMA two tiles ahead
-    MDM_STAGE_TILE(smem);
-    if (ntiles > 1) MDM_STAGE_TILE(smem + STAGE);
-    int cur_i = 0;
-    for (int kt = 0; kt < ntiles; ++kt) {
-      // retire tile kt (issued two iterations ago); tile kt+1 (AJ+BJ loads per lane) may stay in flight
-      if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AJ + BJ) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done reading tile kt-1
-      if (kt + 2 < ntiles) {
-        int nxt = cur_i + 2; if (nxt >= 3) nxt -= 3;
-        MDM_STAGE_TILE(smem + nxt * STAGE);
-      }
-      MDM_COMPUTE_TILE(smem + cur_i * STAGE);
-      if (++cur_i == 3) cur_i = 0;
-    }
-    __syncthreads();   // LDS is reused by the epilogue
+  MDM_STAGE_TILE(smem);
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE;
+    if (kt + 1 < ntiles) MDM_STAGE_TILE(smem + ((kt + 1) & 1) * STAGE);
+    MDM_COMPUTE_TILE(cur);
+    __syncthreads();   // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
   }
 #undef MDM_COMPUTE_TILE
 #undef MDM_STAGE_TILE
@@ -629,71 +545,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
 #undef MDM_TILE_STATE
 #undef MDM_BLDS
 #endif
-}
-
-// 8 consecutive bf16 of a row -> MFMA fragment (zeros when !valid); p must stay a mapped address
-__device__ __forceinline__ void frag_ld(Frag<bf16>& f, const bf16* p, bool valid) {
-  const uint4 z = {0u, 0u, 0u, 0u};
-  const uint4 r = valid ? *reinterpret_cast<const uint4*>(p) : z;
-  f.v = __builtin_bit_cast(bf16x8, r);
-}
-
-// ---------------------------------------------------------------------------
-// EXPERIMENTAL (MDM_HIP_SMALLM=1, off by default -- see mdm_conv_fwd).
-// Linear layer on a handful of rows (M <= 64: the time-embedding MLP, every ResNet's time_layer, the pooled-text
-// projection -- unet.py:206,605-609,763; ~50 launches per step).  The tiled GEMM gives such a problem N/128 blocks
-// that each walk the whole K serially behind a barrier per k-tile (25 us for 3 MB of weights).  Here one block owns
-// 16 output columns, its 4 waves split K (k-steps w, w+4, ...), fragments come straight from global memory (x is
-// L2-resident, every weight row is read exactly once) with 4 k-steps of loads in flight, and the partial sums meet
-// in LDS in a fixed order.  y[m, n] = sum_k x[m, k] * W[n, k] + bias[n], bf16 in / out, fp32 accumulation.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void linear_smallm_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
-                                                            const float* __restrict__ bias, bf16* __restrict__ y,
-                                                            int M, int N, int K) {
-  __shared__ float part[4][64][17];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int quad = lane >> 4, l16 = lane & 15;
-  const int n0 = blockIdx.x * 16;
-  f32x4 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int ksteps = K / 32;
-  const bf16* wrow = w + (size_t)(n0 + l16) * K + quad * 8;
-  for (int ks0 = wave; ks0 < ksteps; ks0 += 16) {
-    Frag<bf16> wf[4], xf[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int ks = ks0 + 4 * u;
-      const bool kv = ks < ksteps;
-      frag_ld(wf[u], kv ? wrow + (size_t)ks * 32 : w, kv);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = i * 16 + l16;
-        const bool ok = kv && m < M;
-        frag_ld(xf[u][i], ok ? x + (size_t)m * K + (size_t)ks * 32 + quad * 8 : x, ok);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mma16(acc[i], wf[u], xf[u][i]);
-  }
-  // acc[i][e] = partial y[m = i*16 + l16][n = n0 + quad*4 + e]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) part[wave][i * 16 + l16][quad * 4 + e] = acc[i][e];
-  __syncthreads();
-  const int row = tid >> 2, c4 = (tid & 3) * 4;
-  if (row < M) {
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = part[0][row][c4 + e] + part[1][row][c4 + e] + part[2][row][c4 + e] + part[3][row][c4 + e];
-      if (bias) v[e] += bias[n0 + c4 + e];
-    }
-    *reinterpret_cast<bf16x4*>(y + (size_t)row * N + n0 + c4) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1691,66 +1542,39 @@ using namespace mdm;
 static thread_local char g_last_gemm[96] = "";
 extern "C" const char* mdm_last_gemm_kernel(void) { return g_last_gemm; }
 #define MDM_NOTE_KERNEL(...) snprintf(g_last_gemm, sizeof(g_last_gemm), __VA_ARGS__)
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int NSTAGE, bool PP = false>
+template <typename T, int BM, int BN, int WM, int WN, int MODE>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
-  constexpr int smem = NSTAGE * (BM + BN) * 128;
-  auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, MODE, NSTAGE, PP>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_done = true;
-  }
+  constexpr int smem = 2 * (BM + BN) * 128;
+  auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, MODE>;
+  ensure_dynamic_lds(kern, smem);
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), smem, st, a);
-  MDM_NOTE_KERNEL("conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : "float", BM, BN, WM, WN, MODE, NSTAGE, (int)PP);
+  MDM_NOTE_KERNEL("conv_gemm_kernel<%s, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : "float", BM, BN, WM, WN, MODE);
   MDM_LAUNCH_STATUS();
-}
-
-static int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
-            ? pr.multiProcessorCount : 256;
-  }
-  return n;
 }
 
 template <int BM, int BN, int WM, int WN, int MODE>
 static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_done = true;
-  }
+  ensure_dynamic_lds(kern, smem);
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-  static int persist = -1;
-  if (persist < 0) { const char* e = getenv("MDM_HIP_PERSIST"); persist = e ? atoi(e) : 1; }   // 0: one block per tile (A/B testing)
-  const int resident = persist ? num_cus() * (WM * WN == 4 ? 2 : 1) : tiles;   // persistent blocks: one (8 waves) or two (4 waves) per CU
+  const int resident = device_cus() * (WM * WN == 4 ? 2 : 1);   // persistent blocks: one (8 waves) or two (4 waves) per CU
   hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a);
   MDM_NOTE_KERNEL("conv_gemm_bl_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, MODE);
   MDM_LAUNCH_STATUS();
 }
 
-static int g_bl = -1;   // MDM_HIP_BLGEMM=0 falls back to the flat-address loader everywhere (A/B testing)
-
 // buffer-addressed k-loop (conv_gemm_bl_kernel) usable for this problem?
 template <typename T, int MODE>
 static bool conv_bl_ok(const ConvArgs& a) {
-  if (g_bl < 0) { const char* e = getenv("MDM_HIP_BLGEMM"); g_bl = e ? atoi(e) : 1; }
-  if (!g_bl || sizeof(T) != 2 || MODE == MODE_3x3_T2 || (a.dbg & 3)) return false;
+  if (sizeof(T) != 2 || MODE == MODE_3x3_T2) return false;
   if (a.K % 64 != 0 || (MODE == MODE_3x3 && a.kblk == 0)) return false;
   const size_t lim = 0x7F000000u;
   const size_t bias = MODE == MODE_3x3 ? (size_t)(a.W + 1) * a.Cin * 2 : 0;
   if ((size_t)a.N * a.H * a.W * a.Cin * 2 + bias > lim || (size_t)a.Cout * a.K * 2 > lim) return false;
   return 2 * bias + (size_t)a.K * 2 < 0x00F00000u;   // INVALID + any tile offset stays below 2^31
 }
-
-static int g_big_tile = -1;   // MDM_HIP_BIGTILE=0 forces the 128x128 kernel, MDM_HIP_TILE=<code> any tile (A/B testing)
-static int g_force_tile = -1;
 
 // Block tile (BM * 1000 + BN) of the forward / dgrad kernel for a problem.  bf16: the candidates are 128x128
 // (2 blocks / CU), 256x192 and 256x256 (1 block / CU); the cheapest by rounds x tile area / relative efficiency wins
@@ -1759,15 +1583,7 @@ static int g_force_tile = -1;
 static int conv_tile_code(int M, int Cout, int dtype) {
   if (Cout <= 32) return 128032;
   if (Cout <= 64) return 128064;
-  if (g_big_tile < 0) {
-    const char* e = getenv("MDM_HIP_BIGTILE");
-    g_big_tile = e ? atoi(e) : 2;
-    const char* f = getenv("MDM_HIP_TILE");
-    g_force_tile = f ? atoi(f) : 0;
-  }
-  if (dtype != DT_BF16 || g_big_tile == 0) return 128128;
-  if (g_force_tile) return g_force_tile;
-  if (g_big_tile == 1) return ((long)((M + 255) / 256) * ((Cout + 127) / 128) >= 256) ? 256128 : 128128;
+  if (dtype != DT_BF16) return 128128;
   const long mt128 = (M + 127) / 128, mt256 = (M + 255) / 256;
   const long t128 = mt128 * ((Cout + 127) / 128), t192 = mt256 * ((Cout + 191) / 192), t256 = mt256 * ((Cout + 255) / 256);
   const double c128 = (double)((t128 + 511) / 512) * 2.0 * 1.0 / 0.80;
@@ -1782,25 +1598,21 @@ extern "C" int mdm_conv_fwd_tile(int M, int Cout, int dtype) { return conv_tile_
 
 template <typename T, int MODE>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
-  if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE, 2>(a, st);
-  if (a.Cout <= 64) return launch_conv_cfg<T, 128, 64, 2, 2, MODE, 2>(a, st);
+  if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE>(a, st);
+  if (a.Cout <= 64) return launch_conv_cfg<T, 128, 64, 2, 2, MODE>(a, st);
   const int code = conv_tile_code(a.M, a.Cout, sizeof(T) == 2 ? DT_BF16 : DT_F32);
   if constexpr (sizeof(T) == 2) {
-    bool bl = false;
-    if constexpr (MODE != MODE_3x3_T2) bl = conv_bl_ok<T, MODE>(a);
     if constexpr (MODE != MODE_3x3_T2) {
-      if (bl && code == 256256) return launch_conv_bl<256, 256, 2, 4, MODE>(a, st);
-      if (bl && code == 256192) return launch_conv_bl<256, 192, 2, 4, MODE>(a, st);
-      if (bl && code == 128128) return launch_conv_bl<128, 128, 2, 2, MODE>(a, st);
+      if (conv_bl_ok<T, MODE>(a)) {
+        if (code == 256256) return launch_conv_bl<256, 256, 2, 4, MODE>(a, st);
+        if (code == 256192) return launch_conv_bl<256, 192, 2, 4, MODE>(a, st);
+        return launch_conv_bl<128, 128, 2, 2, MODE>(a, st);
+      }
     }
-    if (code == 256256 || (code == 256192 && (long)((a.M + 255) / 256) * ((a.Cout + 255) / 256) >= 200)) {
-      static int pp = -1;
-      if (pp < 0) { const char* e = getenv("MDM_HIP_PINGPONG"); pp = e ? atoi(e) : 0; }   // measured equal to the plain schedule; off by default
-      return pp ? launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2, true>(a, st) : launch_conv_cfg<T, 256, 256, 2, 4, MODE, 2, false>(a, st);
-    }
+    // problems the buffer-addressed loader cannot express (ragged K, transposed stride-2 gradient, > 2 GiB operands)
+    if (code != 128128) return launch_conv_cfg<T, 256, 256, 2, 4, MODE>(a, st);
   }
-  if (code == 256128) return launch_conv_cfg<T, 256, 128, 4, 2, MODE, 3>(a, st);
-  return launch_conv_cfg<T, 128, 128, 2, 2, MODE, 2>(a, st);
+  return launch_conv_cfg<T, 128, 128, 2, 2, MODE>(a, st);
 }
 
 template <typename T>
@@ -1832,44 +1644,22 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
   const int bk = dtype == DT_F32 ? 32 : 64;
   MDM_CHECK_ARG(kblock == 0 || (ksize == 3 && kblock == bk && Cin % bk == 0));
   a.kblk = kblock;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("MDM_HIP_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
-  a.dbg = dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static int smallm = -1;
-  // EXPERIMENT, off by default: numerically verified (tests/test_ops_gpu.py::test_linear_small_rows with
-  // MDM_HIP_SMALLM=1), but its only step-level A/B (124.8 vs 106.1 ms/step, run first on a box on which everything
-  // was slow that day) was inconclusive and the GPU budget ended there -- re-measure before enabling.
-  if (smallm < 0) { const char* e = getenv("MDM_HIP_SMALLM"); smallm = e ? atoi(e) : 0; }
-  if (smallm && dtype == DT_BF16 && ksize == 1 && a.M <= 64 && act == 0 && !res && !aux && !y_pre && a.K % 32 == 0 &&
-      Cout % 16 == 0 && !dbg) {
-    hipLaunchKernelGGL(linear_smallm_kernel, dim3(Cout / 16), dim3(256), 0, st, (const bf16*)x, (const bf16*)w_packed, bias,
-                       (bf16*)y, a.M, Cout, a.K);
-    MDM_NOTE_KERNEL("linear_smallm_kernel");
-    MDM_LAUNCH_STATUS();
-  }
   return dtype == DT_F32 ? launch_conv_t<float>(a, ksize, transposed, st) : launch_conv_t<bf16>(a, ksize, transposed, st);
 }
 
 // workspace size (bytes) the caller must provide to mdm_conv_wgrad
-static int g_wgrad_big = -1;   // MDM_HIP_WGRAD_BIG=0 disables the 256x256 wgrad tile (A/B testing)
-
 // Tile edge (128: 4 waves, 2 blocks / CU; 256: bf16 8-wave kernel, 1 block / CU) and split count of a problem, by a
 // small cost model in microseconds: rounds of resident blocks x (reduction tiles per split x tile time + per-block
 // prologue and slab write) + the slab traffic of the reduce kernel.  Replaces "about 2 blocks per CU": at
 // Cout x K = 768 x 3072 that rule gave 15 splits = 540 blocks = 2.1 rounds of the 256 CUs.
 static void wgrad_choose(int M, int Cout, int K, int dtype, int* te_out, int* splits_out) {
-  if (g_wgrad_big < 0) {
-    const char* e = getenv("MDM_HIP_WGRAD_BIG");
-    g_wgrad_big = e ? atoi(e) : 1;   // 0: 128 only, 2: 256 whenever legal (A/B testing)
-  }
   const int bkm = dtype == DT_F32 ? 32 : 64;
   const int mt_total = (M + bkm - 1) / bkm;
   double best = 1e30;
   int best_te = 128, best_s = 1;
   for (int te = 128; te <= 256; te += 128) {
-    if (te == 256 && !(dtype == DT_BF16 && g_wgrad_big && Cout >= 192 && K >= 192)) continue;
-    if (te == 128 && g_wgrad_big == 2 && dtype == DT_BF16 && Cout >= 192 && K >= 192) continue;
+    if (te == 256 && !(dtype == DT_BF16 && Cout >= 192 && K >= 192)) continue;
     const int tiles = ((Cout + te - 1) / te) * ((K + te - 1) / te);
     const int slots = te == 256 ? 256 : 512;
     const double t_tile = (te == 256 ? 1.7 : 1.06) * (dtype == DT_F32 ? 8.0 : 1.0), t_fix = te == 256 ? 12.0 : 5.0;
@@ -1905,17 +1695,10 @@ extern "C" int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* split
   return 0;
 }
 
-template <typename K>
-static void wgrad_set_smem(K kern, int bytes) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
-
 extern "C" int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulate, int dtype, void* stream);
 
 // buffer-addressed wgrad (conv_wgrad_bl_kernel) usable for this bf16 problem?
 static bool wgrad_bl_ok(const WgradArgs& a, int ksize) {
-  if (g_bl < 0) { const char* e = getenv("MDM_HIP_BLGEMM"); g_bl = e ? atoi(e) : 1; }
-  if (!g_bl) return false;
   if (ksize == 3) {
     if (a.stride != 1 || a.Ho != a.H || a.Wo != a.W) return false;
     if ((a.H & (a.H - 1)) || (a.W & (a.W - 1))) return false;
@@ -1948,20 +1731,16 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, floa
   const int tiles = ((Cout + te - 1) / te) * ((a.K + te - 1) / te);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   constexpr int smem = 4 * 128 * 128, smem_big = 4 * 64 * 512;
-  static bool attr_done = false;
-  if (!attr_done) {
-    wgrad_set_smem(conv_wgrad_kernel<float, MODE_1x1>, smem);
-    wgrad_set_smem(conv_wgrad_kernel<float, MODE_3x3>, smem);
-    wgrad_set_smem(conv_wgrad_tr_kernel<MODE_1x1, 0>, smem);
-    wgrad_set_smem(conv_wgrad_tr_kernel<MODE_3x3, 0>, smem);
-    wgrad_set_smem(conv_wgrad_tr_kernel<MODE_1x1, 1>, smem_big);
-    wgrad_set_smem(conv_wgrad_tr_kernel<MODE_3x3, 1>, smem_big);
-    wgrad_set_smem(conv_wgrad_bl_kernel<MODE_1x1, 0>, smem);
-    wgrad_set_smem(conv_wgrad_bl_kernel<MODE_3x3, 0>, smem);
-    wgrad_set_smem(conv_wgrad_bl_kernel<MODE_1x1, 1>, smem_big);
-    wgrad_set_smem(conv_wgrad_bl_kernel<MODE_3x3, 1>, smem_big);
-    attr_done = true;
-  }
+  ensure_dynamic_lds(conv_wgrad_kernel<float, MODE_1x1>, smem);
+  ensure_dynamic_lds(conv_wgrad_kernel<float, MODE_3x3>, smem);
+  ensure_dynamic_lds(conv_wgrad_tr_kernel<MODE_1x1, 0>, smem);
+  ensure_dynamic_lds(conv_wgrad_tr_kernel<MODE_3x3, 0>, smem);
+  ensure_dynamic_lds(conv_wgrad_tr_kernel<MODE_1x1, 1>, smem_big);
+  ensure_dynamic_lds(conv_wgrad_tr_kernel<MODE_3x3, 1>, smem_big);
+  ensure_dynamic_lds(conv_wgrad_bl_kernel<MODE_1x1, 0>, smem);
+  ensure_dynamic_lds(conv_wgrad_bl_kernel<MODE_3x3, 0>, smem);
+  ensure_dynamic_lds(conv_wgrad_bl_kernel<MODE_1x1, 1>, smem_big);
+  ensure_dynamic_lds(conv_wgrad_bl_kernel<MODE_3x3, 1>, smem_big);
   dim3 grid(tiles * a.splits);
   const int mode = ksize == 1 ? MODE_1x1 : MODE_3x3;
   if (dtype == DT_F32) MDM_NOTE_KERNEL("conv_wgrad_kernel<float, %d>", mode);

@@ -7,13 +7,20 @@
 //   cross-attn cond     norm_cond = LayerNorm(cond_dim)                            unet.py:263,304
 // nn.GroupNorm(G, C, eps=1e-5, affine), biased variance.
 //
-// All kernels here are HBM-bound streaming kernels: 16-byte loads, fp32 math,
-// deterministic two-stage reductions (per-slab partials -> finalize), no atomics.
+// All kernels here are HBM-bound streaming kernels: 16-byte loads, fp32 math.  Activation-sized reductions are
+// deterministic (fixed-order shuffles / LDS / per-slab partials); only the per-channel parameter gradients
+// (dgamma, dbeta: a sum over the batch of per-sample terms) are accumulated with fp32 hardware atomics.
 //
-// Forward  = gn_partial (reads x) -> gn_finalize (tiny) -> gn_apply (reads x, writes y)
-//   y = act(a[n,c] * x + b[n,c]),  a = gamma*f*rstd, b = (beta - mean*rstd*gamma)*f + tb, f = 1 + ta
-// Backward = gn_bwd_partial (reads dy, x) -> gn_bwd_finalize -> gn_bwd_apply (reads dy, x, writes dx)
-//   dz = dy * act'(a*x + b);  dx = a*dz + q[n,g]*x + r[n,g]
+// Small images (a (sample, <= 64-channel slice) fits one block's registers): ONE kernel each way.
+// Large images: TWO kernels each way --
+//   forward   gn_partial (reads x) -> gn_apply (per-block finalize of its channel slice, reads x, writes y)
+//     y = act(a[n,c] * x + b[n,c]),  a = gamma*f*rstd, b = (beta - mean*rstd*gamma)*f + tb, f = 1 + ta
+//   backward  gn_bwd_partial (reads dy, x) -> gn_bwd_apply (per-block finalize, reads dy, x, dres, writes dx)
+//     dz = dy * act'(a*x + b);  dx = a*dz + q[n,g]*x + r[n,g]
+// Round 1 ran the finalize steps (and the batch reduction of dgamma / dbeta) as separate tiny kernels: 0.4 MB of
+// traffic each, but 50-115 us apiece in the train step, because a dependent 24-block launch on the critical stream
+// queues behind the weight-gradient grids of the side stream.  Every block of the apply kernels now redoes the
+// finalize arithmetic for its own 64-channel slice from the slab partials (8 KB, L2-resident) instead.
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -70,79 +77,87 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   }
 }
 
-// ---- stage 2: one block per n: group statistics + per-channel coefficients ---
-template <typename T>
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ x, const float* __restrict__ part,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const T* __restrict__ film,
-                                                          float* __restrict__ stats, float* __restrict__ coef, int HW,
-                                                          int C, int G, int slabs, float eps) {
-  __shared__ float sh_s1[2048], sh_s2[2048], sh_k[2048];  // C <= 2048 (host-checked)
-  __shared__ float sh_mean[256], sh_rstd[256];            // G <= 256
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const int cpg = C / G;
+// ---- stage 2: finalize (per block, for its channel slice) + y = act(a * x + b) ---------------------------
+// grid (pixel splits, C / CB, N).  A block owns CB channels (whole groups; 128 bytes of every pixel row when the
+// group width allows) of sample n and the pixels [px0, px1).  Prologue: per-channel slab sums -> group mean / rstd
+// (the shifted-sum formulas of the partial kernel) -> coefficients a, b; the block with pixel split 0 also
+// stores stats / coef for the backward pass.
+constexpr int GN_MAXCB = 128;   // channels per block slice (upper bound; host picks CB <= this)
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const T* __restrict__ film, T* __restrict__ y,
+                                                       float* __restrict__ stats, float* __restrict__ coef, int HW, int C,
+                                                       int G, int CB, int slabs, int pix_per_block, float eps) {
+  constexpr int EPV = Tr<T>::EPV;
+  __shared__ float sh_s1[GN_MAXCB], sh_s2[GN_MAXCB], sh_k[GN_MAXCB], sh_a[GN_MAXCB], sh_b[GN_MAXCB];
+  __shared__ float sh_mean[GN_MAXCB], sh_rstd[GN_MAXCB];
+  const int n = blockIdx.z, cb0 = blockIdx.y * CB, tid = threadIdx.x;
+  const int cpg = C / G, gpb = CB / cpg;
   const T* xn = x + (size_t)n * HW * C;
-  for (int c = tid; c < C; c += 256) {
+  if (tid < CB) {
+    const int c = cb0 + tid;
     float a = 0.f, b = 0.f;
-    for (int s = 0; s < slabs; ++s) {
-      const float* pp = part + (((size_t)n * slabs + s) * C + c) * 2;
+    for (int s_ = 0; s_ < slabs; ++s_) {
+      const float* pp = part + (((size_t)n * slabs + s_) * C + c) * 2;
       a += pp[0]; b += pp[1];
     }
-    sh_s1[c] = a; sh_s2[c] = b; sh_k[c] = to_f32(xn[c]);
+    sh_s1[tid] = a; sh_s2[tid] = b; sh_k[tid] = to_f32(xn[c]);
   }
   __syncthreads();
   const float cnt = (float)HW;
-  for (int g = tid; g < G; g += 256) {
+  if (tid < gpb) {
     float mu = 0.f;
-    for (int j = 0; j < cpg; ++j) { const int c = g * cpg + j; mu += sh_k[c] + sh_s1[c] / cnt; }
+    for (int j = 0; j < cpg; ++j) { const int c = tid * cpg + j; mu += sh_k[c] + sh_s1[c] / cnt; }
     mu /= (float)cpg;
     float var = 0.f;
     for (int j = 0; j < cpg; ++j) {
-      const int c = g * cpg + j;
+      const int c = tid * cpg + j;
       const float d = sh_k[c] - mu;
       var += sh_s2[c] + 2.f * d * sh_s1[c] + cnt * d * d;
     }
     var = fmaxf(var / (cnt * (float)cpg), 0.f);
     const float rstd = rsqrtf(var + eps);
-    sh_mean[g] = mu; sh_rstd[g] = rstd;
-    stats[((size_t)n * G + g) * 2] = mu;
-    stats[((size_t)n * G + g) * 2 + 1] = rstd;
+    sh_mean[tid] = mu; sh_rstd[tid] = rstd;
+    if (blockIdx.x == 0) {
+      const int g = cb0 / cpg + tid;
+      stats[((size_t)n * G + g) * 2] = mu;
+      stats[((size_t)n * G + g) * 2 + 1] = rstd;
+    }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cpg;
-    const float mu = sh_mean[g], rstd = sh_rstd[g];
+  if (tid < CB) {
+    const int c = cb0 + tid, gl = tid / cpg;
+    const float mu = sh_mean[gl], rstd = sh_rstd[gl];
     float f = 1.f, tb = 0.f;
     if (film) { f = 1.f + to_f32(film[(size_t)n * 2 * C + c]); tb = to_f32(film[(size_t)n * 2 * C + C + c]); }
     const float ga = gamma[c], be = beta[c];
-    coef[((size_t)n * C + c) * 2] = ga * f * rstd;
-    coef[((size_t)n * C + c) * 2 + 1] = (be - mu * rstd * ga) * f + tb;
+    const float a = ga * f * rstd, b = (be - mu * rstd * ga) * f + tb;
+    sh_a[tid] = a; sh_b[tid] = b;
+    if (blockIdx.x == 0) {
+      coef[((size_t)n * C + c) * 2] = a;
+      coef[((size_t)n * C + c) * 2 + 1] = b;
+    }
   }
-}
-
-// ---- stage 3: y = act(a * x + b) ---------------------------------------------
-template <typename T, int ACT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef,
-                                                       T* __restrict__ y, int HW, int C, size_t total_chunks) {
-  constexpr int EPV = Tr<T>::EPV;
-  const int cchunks = C / EPV;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % cchunks);
-    const size_t pix = i / cchunks;
-    const int n = (int)(pix / HW);
-    Chunk<T> ch;
-    ch.load(x + i * EPV);
-    const float* cf = coef + ((size_t)n * C + (size_t)cc * EPV) * 2;
-    float ab[2 * EPV];
+  __syncthreads();
+  const int lanes = CB / EPV, rows_par = 256 / lanes;
+  const int cl = tid % lanes, rl = tid / lanes;
+  if (rl >= rows_par) return;
+  float a[EPV], b[EPV];
 #pragma unroll
-    for (int e = 0; e < 2 * EPV; e += 4) *reinterpret_cast<f32x4*>(ab + e) = *reinterpret_cast<const f32x4*>(cf + e);
+  for (int e = 0; e < EPV; ++e) { a[e] = sh_a[cl * EPV + e]; b[e] = sh_b[cl * EPV + e]; }
+  const int px0 = blockIdx.x * pix_per_block, px1 = min(HW, px0 + pix_per_block);
+  const size_t base = (size_t)n * HW * C + cb0 + cl * EPV;
+  for (int p = px0 + rl; p < px1; p += rows_par) {
+    Chunk<T> ch;
+    ch.load(x + base + (size_t)p * C);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
-      float z = ab[2 * e] * ch.v[e] + ab[2 * e + 1];
+      const float z = a[e] * ch.v[e] + b[e];
       ch.v[e] = ACT ? silu_f(z) : z;
     }
-    ch.store(y + i * EPV);
+    ch.store(y + base + (size_t)p * C);
   }
 }
 
@@ -201,22 +216,28 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict
   }
 }
 
-// ---- backward stage 2: one block per n ------------------------------------------
-// outputs: qr[n][g] = (q, r); dfilm[n][2C] (if film); pgrad[n][c] = (dgamma_n, dbeta_n)
-template <typename T>
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part,
-                                                              const float* __restrict__ stats,
-                                                              const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, const T* __restrict__ film,
-                                                              float* __restrict__ qr, T* __restrict__ dfilm,
-                                                              float* __restrict__ pgrad, int HW, int C, int G, int slabs) {
-  __shared__ float sh_fgA1[2048], sh_fgXh[2048];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const int cpg = C / G;
-  for (int c = tid; c < C; c += 256) {
+// ---- backward stage 2: finalize (per block, for its channel slice) + dx = a*dz + q*x + r (+ dres) ---------
+// Same decomposition as gn_apply_kernel.  The block with pixel split 0 also emits the parameter-side results of
+// its slice: dfilm[n] (stores) and this sample's terms of dgamma / dbeta (fp32 atomic adds: the destination is the
+// parameter's gradient-arena slot or a zero-filled buffer).
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const float* __restrict__ part, const float* __restrict__ stats,
+                                                           const float* __restrict__ coef, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const T* __restrict__ film,
+                                                           const T* __restrict__ dres, T* __restrict__ dx,
+                                                           T* __restrict__ dfilm, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int HW, int C, int G, int CB,
+                                                           int slabs, int pix_per_block) {
+  constexpr int EPV = Tr<T>::EPV;
+  __shared__ float sh_fgA1[GN_MAXCB], sh_fgXh[GN_MAXCB], sh_a[GN_MAXCB], sh_b[GN_MAXCB], sh_q[GN_MAXCB], sh_r[GN_MAXCB];
+  const int n = blockIdx.z, cb0 = blockIdx.y * CB, tid = threadIdx.x;
+  const int cpg = C / G, gpb = CB / cpg;
+  if (tid < CB) {
+    const int c = cb0 + tid;
     float A1 = 0.f, A2 = 0.f;
-    for (int s = 0; s < slabs; ++s) {
-      const float* pp = part + (((size_t)n * slabs + s) * C + c) * 2;
+    for (int s_ = 0; s_ < slabs; ++s_) {
+      const float* pp = part + (((size_t)n * slabs + s_) * C + c) * 2;
       A1 += pp[0]; A2 += pp[1];
     }
     const int g = c / cpg;
@@ -225,87 +246,60 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
     float f = 1.f;
     if (film) f = 1.f + to_f32(film[(size_t)n * 2 * C + c]);
     const float ga = gamma[c], be = beta[c];
-    pgrad[((size_t)n * C + c) * 2] = f * Xh;
-    pgrad[((size_t)n * C + c) * 2 + 1] = f * A1;
-    if (film) {
-      dfilm[(size_t)n * 2 * C + c] = from_f32<T>(ga * Xh + be * A1);
-      dfilm[(size_t)n * 2 * C + C + c] = from_f32<T>(A1);
+    if (blockIdx.x == 0) {
+      unsafeAtomicAdd(dgamma + c, f * Xh);
+      unsafeAtomicAdd(dbeta + c, f * A1);
+      if (film) {
+        dfilm[(size_t)n * 2 * C + c] = from_f32<T>(ga * Xh + be * A1);
+        dfilm[(size_t)n * 2 * C + C + c] = from_f32<T>(A1);
+      }
     }
-    sh_fgA1[c] = f * ga * A1;
-    sh_fgXh[c] = f * ga * Xh;
+    sh_fgA1[tid] = f * ga * A1;
+    sh_fgXh[tid] = f * ga * Xh;
+    sh_a[tid] = coef[((size_t)n * C + c) * 2];
+    sh_b[tid] = coef[((size_t)n * C + c) * 2 + 1];
   }
   __syncthreads();
-  const float m = (float)cpg * (float)HW;
-  for (int g = tid; g < G; g += 256) {
+  if (tid < gpb) {
     float S1 = 0.f, S2 = 0.f;
-    for (int j = 0; j < cpg; ++j) { S1 += sh_fgA1[g * cpg + j]; S2 += sh_fgXh[g * cpg + j]; }
+    for (int j = 0; j < cpg; ++j) { S1 += sh_fgA1[tid * cpg + j]; S2 += sh_fgXh[tid * cpg + j]; }
+    const int g = cb0 / cpg + tid;
     const float mu = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
+    const float m = (float)cpg * (float)HW;
     const float q = -rstd * rstd * S2 / m;
-    qr[((size_t)n * G + g) * 2] = q;
-    qr[((size_t)n * G + g) * 2 + 1] = -rstd * S1 / m - q * mu;
+    sh_q[tid] = q;
+    sh_r[tid] = -rstd * S1 / m - q * mu;
   }
-}
-
-// dgamma[c] = sum_n pgrad[n][c][0]; dbeta[c] = sum_n pgrad[n][c][1]
-// block = 32 channels x 8 interleaved sample ranges (256 threads), fixed-order LDS reduction
-__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ pgrad, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int N, int C, int accumulate) {
-  __shared__ float red[8][32][2];
-  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  float a = 0.f, b = 0.f;
-  if (c < C)
-    for (int n = part; n < N; n += 8) {
-      const f32x2 v = *reinterpret_cast<const f32x2*>(pgrad + ((size_t)n * C + c) * 2);
-      a += v[0]; b += v[1];
-    }
-  red[part][cl][0] = a; red[part][cl][1] = b;
   __syncthreads();
-  if (part == 0 && c < C) {
+  const int lanes = CB / EPV, rows_par = 256 / lanes;
+  const int cl = tid % lanes, rl = tid / lanes;
+  if (rl >= rows_par) return;
+  float a[EPV], b[EPV], q[EPV], r[EPV];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) { a += red[q][cl][0]; b += red[q][cl][1]; }
-    dgamma[c] = accumulate ? dgamma[c] + a : a;
-    dbeta[c] = accumulate ? dbeta[c] + b : b;
+  for (int e = 0; e < EPV; ++e) {
+    const int c = cl * EPV + e;
+    a[e] = sh_a[c]; b[e] = sh_b[c]; q[e] = sh_q[c / cpg]; r[e] = sh_r[c / cpg];
   }
-}
-
-// ---- backward stage 3: dx = a*dz + q*x + r ------------------------------------------
-template <typename T, int ACT>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                           const float* __restrict__ coef,
-                                                           const float* __restrict__ qr, T* __restrict__ dx,
-                                                           const T* __restrict__ dres, int HW, int C, int G,
-                                                           size_t total_chunks) {
-  constexpr int EPV = Tr<T>::EPV;
-  const int cchunks = C / EPV;
-  const int cpg = C / G;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % cchunks);
-    const size_t pix = i / cchunks;
-    const int n = (int)(pix / HW);
+  const int px0 = blockIdx.x * pix_per_block, px1 = min(HW, px0 + pix_per_block);
+  const size_t base = (size_t)n * HW * C + cb0 + cl * EPV;
+  for (int p = px0 + rl; p < px1; p += rows_par) {
+    const size_t off = base + (size_t)p * C;
     Chunk<T> cx, cd;
-    cx.load(x + i * EPV);
-    cd.load(dy + i * EPV);
-    const float* cf = coef + ((size_t)n * C + (size_t)cc * EPV) * 2;
-    float ab[2 * EPV];
-#pragma unroll
-    for (int e = 0; e < 2 * EPV; e += 4) *reinterpret_cast<f32x4*>(ab + e) = *reinterpret_cast<const f32x4*>(cf + e);
+    cx.load(x + off);
+    cd.load(dy + off);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
-      const int g = (cc * EPV + e) / cpg;
-      const float q = qr[((size_t)n * G + g) * 2], r = qr[((size_t)n * G + g) * 2 + 1];
       float dz = cd.v[e];
-      if (ACT) dz *= dsilu_f(ab[2 * e] * cx.v[e] + ab[2 * e + 1]);
-      cd.v[e] = ab[2 * e] * dz + q * cx.v[e] + r;
+      if (ACT) dz *= dsilu_f(a[e] * cx.v[e] + b[e]);
+      cd.v[e] = a[e] * dz + q[e] * cx.v[e] + r[e];
     }
     if (dres) {
       Chunk<T> cr;
-      cr.load(dres + i * EPV);
+      cr.load(dres + off);
 #pragma unroll
       for (int e = 0; e < EPV; ++e) cd.v[e] += cr.v[e];
     }
-    cd.store(dx + i * EPV);
+    cd.store(dx + off);
   }
 }
 
@@ -439,8 +433,9 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const T* __restrict__ film, const float* __restrict__ stats,
                                                             const float* __restrict__ coef, T* __restrict__ dx,
-                                                            T* __restrict__ dfilm, float* __restrict__ pgrad,
-                                                            const T* __restrict__ dres, int HW, int C, int G, int CB) {
+                                                            T* __restrict__ dfilm, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, const T* __restrict__ dres,
+                                                            int HW, int C, int G, int CB) {
   constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = NTHR / LPR, NW = NTHR / 64;
   __shared__ float sh[NW][LPR][2 * EPV];
   __shared__ float tot[LPR][2 * EPV];
@@ -507,8 +502,9 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
     if (film) f = 1.f + to_f32(film[(size_t)n * 2 * C + ch]);
     const float ga = gamma[ch], be = beta[ch];
     if (r == 0 && active) {
-      pgrad[((size_t)n * C + ch) * 2] = f * Xh;
-      pgrad[((size_t)n * C + ch) * 2 + 1] = f * a1;
+      // this sample's term of the parameter gradients (destination: gradient-arena slot or a zero-filled buffer)
+      unsafeAtomicAdd(dgamma + ch, f * Xh);
+      unsafeAtomicAdd(dbeta + ch, f * a1);
       if (film) {
         dfilm[(size_t)n * 2 * C + ch] = from_f32<T>(ga * Xh + be * a1);
         dfilm[(size_t)n * 2 * C + C + ch] = from_f32<T>(a1);
@@ -551,9 +547,6 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
 
 // channels per block of the fused kernels (0 = not applicable -> three-kernel path)
 static int gn_fused_cb(int HW, int C, int G, int dtype, int max_ni) {
-  static int enabled = -1;
-  if (enabled < 0) { const char* e = getenv("MDM_HIP_GN_FUSED"); enabled = e ? atoi(e) : 1; }
-  if (!enabled) return 0;
   const int epv = dtype == DT_F32 ? 4 : 8, lpr = dtype == DT_F32 ? 16 : 8;
   const int cpg = C / G;
   if (cpg % epv != 0 || cpg > lpr * epv) return 0;
@@ -655,11 +648,35 @@ static inline int gn_slabs(int N, int HW) {
   return s;
 }
 
-// workspace (bytes, fp32): part [N][slabs][C][2] + pgrad [N][C][2] + qr [N][G][2]
+// channel slice of an apply block: whole groups, whole 16-byte chunks, 128 bytes per pixel row when the group width
+// allows it (64 bf16 / 32 fp32 channels), never more than GN_MAXCB; 0 = this (C, G) is not supported
+static inline int gn_slice(int C, int G, int epv) {
+  const int cpg = C / G, target = epv * 8;
+  int best = 0;
+  for (int j = 1; j <= G; ++j) {
+    if (G % j != 0) continue;
+    const int cb = cpg * j;
+    if (cb % epv != 0 || cb > GN_MAXCB) continue;
+    best = cb;                       // largest legal slice so far
+    if (cb >= target) break;         // first one that fills a 128-byte line
+  }
+  return best;
+}
+
+// pixel splits of the apply grid: about 2048 blocks in total, at least 64 pixels per block
+static inline int gn_pix_splits(int N, int HW, int cslices) {
+  int sp = (2048 + N * cslices - 1) / (N * cslices);
+  const int max_sp = (HW + 63) / 64;
+  if (sp > max_sp) sp = max_sp;
+  if (sp < 1) sp = 1;
+  return sp;
+}
+
+// workspace (bytes, fp32): part [N][slabs][C][2]
 extern "C" int mdm_gn_plan(int N, int HW, int C, int G, size_t* ws_bytes) {
   MDM_CHECK_ARG(ws_bytes);
   const int slabs = gn_slabs(N, HW);
-  *ws_bytes = ((size_t)N * slabs * C * 2 + (size_t)N * C * 2 + (size_t)N * G * 2) * sizeof(float);
+  *ws_bytes = ((size_t)N * slabs * C * 2) * sizeof(float);
   return 0;
 }
 
@@ -672,8 +689,6 @@ extern "C" int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, 
   const int epv = dtype == DT_F32 ? 4 : 8;
   MDM_CHECK_ARG(C % epv == 0 && C % G == 0 && C <= 2048 && G <= 256);
   MDM_CHECK_ARG(act == 0 || act == 1);
-  const int slabs = gn_slabs(N, HW);
-  const int pps = (HW + slabs - 1) / slabs;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (const int cb = gn_fused_cb(HW, C, G, dtype, 8)) {
     const dim3 grid(N, C / cb);
@@ -688,22 +703,25 @@ extern "C" int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, 
 #undef MDM_GN_FUSED_FWD
     MDM_LAUNCH_STATUS();
   }
-  const size_t total_chunks = (size_t)N * HW * C / epv;
-  const int ab = (int)((total_chunks + 255) / 256 > 16384 ? 16384 : (total_chunks + 255) / 256);
-  if (dtype == DT_F32) {
-    hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(N * slabs), dim3(256), 0, st, (const float*)x, ws, HW, C, slabs, pps);
-    hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(N), dim3(256), 0, st, (const float*)x, ws, gamma, beta, (const float*)film, stats, coef, HW, C, G, slabs, eps);
-    if (act) hipLaunchKernelGGL((gn_apply_kernel<float, 1>), dim3(ab), dim3(256), 0, st, (const float*)x, coef, (float*)y, HW, C, total_chunks);
-    else hipLaunchKernelGGL((gn_apply_kernel<float, 0>), dim3(ab), dim3(256), 0, st, (const float*)x, coef, (float*)y, HW, C, total_chunks);
-  } else {
-    hipLaunchKernelGGL(gn_partial_kernel<bf16>, dim3(N * slabs), dim3(256), 0, st, (const bf16*)x, ws, HW, C, slabs, pps);
-    hipLaunchKernelGGL(gn_finalize_kernel<bf16>, dim3(N), dim3(256), 0, st, (const bf16*)x, ws, gamma, beta, (const bf16*)film, stats, coef, HW, C, G, slabs, eps);
-    if (act) hipLaunchKernelGGL((gn_apply_kernel<bf16, 1>), dim3(ab), dim3(256), 0, st, (const bf16*)x, coef, (bf16*)y, HW, C, total_chunks);
-    else hipLaunchKernelGGL((gn_apply_kernel<bf16, 0>), dim3(ab), dim3(256), 0, st, (const bf16*)x, coef, (bf16*)y, HW, C, total_chunks);
-  }
+  const int slabs = gn_slabs(N, HW);
+  const int pps = (HW + slabs - 1) / slabs;
+  const int cb = gn_slice(C, G, epv);
+  MDM_CHECK_ARG(cb > 0);
+  const int sp = gn_pix_splits(N, HW, C / cb);
+  const int ppb = (HW + sp - 1) / sp;
+  const dim3 agrid(sp, C / cb, N);
+#define MDM_GN_FWD(TT, ACT)                                                                                          \
+  hipLaunchKernelGGL(gn_partial_kernel<TT>, dim3(N * slabs), dim3(256), 0, st, (const TT*)x, ws, HW, C, slabs, pps); \
+  hipLaunchKernelGGL((gn_apply_kernel<TT, ACT>), agrid, dim3(256), 0, st, (const TT*)x, ws, gamma, beta,             \
+                     (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, slabs, ppb, eps);
+  if (dtype == DT_F32) { if (act) { MDM_GN_FWD(float, 1) } else { MDM_GN_FWD(float, 0) } }
+  else { if (act) { MDM_GN_FWD(bf16, 1) } else { MDM_GN_FWD(bf16, 0) } }
+#undef MDM_GN_FWD
   MDM_LAUNCH_STATUS();
 }
 
+// dgamma / dbeta: `accumulate` != 0 adds into the destination (a gradient-arena slot); otherwise the destination is
+// zero-filled first (the kernels add one term per sample with fp32 atomics).
 extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* film,
                           const float* stats, const float* coef, const void* dres, void* dx, float* dgamma,
                           float* dbeta, void* dfilm, float* ws, int N, int HW, int C, int G, int act, int accumulate,
@@ -713,37 +731,40 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
   MDM_CHECK_ARG((film == nullptr) == (dfilm == nullptr));
   const int epv = dtype == DT_F32 ? 4 : 8;
   MDM_CHECK_ARG(C % epv == 0 && C % G == 0 && C <= 2048 && G <= 256);
-  const int slabs = gn_slabs(N, HW);
-  const int pps = (HW + slabs - 1) / slabs;
-  float* part = ws;
-  float* pgrad = ws + (size_t)N * slabs * C * 2;
-  float* qr = pgrad + (size_t)N * C * 2;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // x AND dy stay in registers here: 4 passes at most (beyond that the register file spills; three-kernel path)
+  if (!accumulate) {
+    if (hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), st) != hipSuccess) {
+      mdm_set_error(__FILE__, __LINE__, "hipMemsetAsync(dgamma / dbeta)");
+      return (int)hipGetLastError();
+    }
+  }
+  // x AND dy stay in registers here: 4 passes at most (beyond that the register file spills; two-kernel path)
   if (const int cb = gn_fused_cb(HW, C, G, dtype, 4)) {
     const dim3 grid(N, C / cb);
     const int lpr = dtype == DT_F32 ? 16 : 8;
     const int nthr = HW <= 4 * (512 / lpr) ? 512 : 1024;
 #define MDM_GN_FUSED_BWD(TT, ACT)                                                                                  \
-    if (nthr == 512) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 512>), grid, dim3(512), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, pgrad, (const TT*)dres, HW, C, G, cb); \
-    else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 1024>), grid, dim3(1024), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, pgrad, (const TT*)dres, HW, C, G, cb)
+    if (nthr == 512) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 512>), grid, dim3(512), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, dgamma, dbeta, (const TT*)dres, HW, C, G, cb); \
+    else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 1024>), grid, dim3(1024), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, dgamma, dbeta, (const TT*)dres, HW, C, G, cb)
     if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_BWD(float, 1); } else { MDM_GN_FUSED_BWD(float, 0); } }
     else { if (act) { MDM_GN_FUSED_BWD(bf16, 1); } else { MDM_GN_FUSED_BWD(bf16, 0); } }
 #undef MDM_GN_FUSED_BWD
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pgrad, dgamma, dbeta, N, C, accumulate);
     MDM_LAUNCH_STATUS();
   }
-  const size_t total_chunks = (size_t)N * HW * C / epv;
-  const int ab = (int)((total_chunks + 255) / 256 > 16384 ? 16384 : (total_chunks + 255) / 256);
+  const int slabs = gn_slabs(N, HW);
+  const int pps = (HW + slabs - 1) / slabs;
+  const int cb = gn_slice(C, G, epv);
+  MDM_CHECK_ARG(cb > 0);
+  const int sp = gn_pix_splits(N, HW, C / cb);
+  const int ppb = (HW + sp - 1) / sp;
+  const dim3 agrid(sp, C / cb, N);
 #define MDM_GN_BWD(TT, ACT)                                                                                          \
   hipLaunchKernelGGL((gn_bwd_partial_kernel<TT, ACT>), dim3(N * slabs), dim3(256), 0, st, (const TT*)dy,             \
-                     (const TT*)x, coef, part, HW, C, slabs, pps);                                                   \
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel<TT>, dim3(N), dim3(256), 0, st, part, stats, gamma, beta,                \
-                     (const TT*)film, qr, (TT*)dfilm, pgrad, HW, C, G, slabs);                                       \
-  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pgrad, dgamma, dbeta, N, C,        \
-                     accumulate);                                                                                    \
-  hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, ACT>), dim3(ab), dim3(256), 0, st, (const TT*)dy, (const TT*)x, coef, \
-                     qr, (TT*)dx, (const TT*)dres, HW, C, G, total_chunks);
+                     (const TT*)x, coef, ws, HW, C, slabs, pps);                                                     \
+  hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, ACT>), agrid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, ws, stats, \
+                     coef, gamma, beta, (const TT*)film, (const TT*)dres, (TT*)dx, (TT*)dfilm, dgamma, dbeta, HW, C, G,  \
+                     cb, slabs, ppb);
   if (dtype == DT_F32) { if (act) { MDM_GN_BWD(float, 1) } else { MDM_GN_BWD(float, 0) } }
   else { if (act) { MDM_GN_BWD(bf16, 1) } else { MDM_GN_BWD(bf16, 0) } }
 #undef MDM_GN_BWD

@@ -64,14 +64,24 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   float gs = 1.f;
+  bool poisoned = false;
   if (a.gnorm_sq) {
-    const float nrm = sqrtf(a.gnorm_sq[0]);
+    const float q = a.gnorm_sq[0];
+    poisoned = !(q == q) || q > 3.0e38f;       // NaN / inf gradient norm: one bad sample must not wipe out p, m, v, ema
+    const float nrm = sqrtf(q);
     gs = fminf(a.clip / (nrm + 1e-6f), 1.f);   // torch.nn.utils.clip_grad_norm_ coefficient
   }
   const bool has_ema = a.ema != nullptr;
   const size_t n4 = a.n / 4;
   f32x4* p4 = reinterpret_cast<f32x4*>(a.p);
   f32x4* g4 = reinterpret_cast<f32x4*>(a.g);
+  if (poisoned) {   // skip the update, only clear the gradients
+    if (a.zero_grad) {
+      for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) g4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (blockIdx.x == 0) for (size_t i = n4 * 4 + threadIdx.x; i < a.n; i += 256) a.g[i] = 0.f;
+    }
+    return;
+  }
   f32x4* m4 = reinterpret_cast<f32x4*>(a.m);
   f32x4* v4 = reinterpret_cast<f32x4*>(a.v);
   f32x4* e4 = reinterpret_cast<f32x4*>(a.ema);

@@ -13,9 +13,10 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-HEADER = os.path.join(_ROOT, "include", "mdm_hip.h")
+HEADER = os.path.join(_ROOT, "include", "mdm_hip.h")            # the drop-in boundary
+DEV_HEADER = os.path.join(_ROOT, "include", "mdm_hip_dev.h")    # profiling aids (bench.py, tools/)
 LIB_PATH = os.path.join(_HERE, "libmdm_hip.so")
-SOURCES = ["gemm_conv.hip", "norm.hip", "attention.hip", "elementwise.hip", "optim.hip"]
+SOURCES = ["gemm_conv.hip", "norm.hip", "attention.hip", "elementwise.hip", "optim.hip", "diffusion_ops.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -63,6 +64,7 @@ _CTYPES = {
     "int": ctypes.c_int,
     "float": ctypes.c_float,
     "size_t": ctypes.c_size_t,
+    "unsigned long long": ctypes.c_ulonglong,
 }
 
 
@@ -73,8 +75,8 @@ def _ctype_of(decl: str):
         if base == "char":
             return ctypes.c_char_p
         return ctypes.c_void_p
-    base = decl.replace("const", "").split()[0]
-    return _CTYPES[base]
+    words = decl.replace("const", "").split()[:-1]   # drop the parameter name
+    return _CTYPES[" ".join(words)]
 
 
 def header_prototypes(path: str = HEADER):
@@ -110,7 +112,7 @@ def lib():
                 "-- there is no CPU fallback for the product path." % LIB_PATH
             )
         handle = ctypes.CDLL(LIB_PATH)
-        for name, restype, argtypes, _ in header_prototypes():
+        for name, restype, argtypes, _ in header_prototypes() + header_prototypes(DEV_HEADER):
             fn = getattr(handle, name)  # AttributeError if the header and the library drift
             fn.restype = restype
             fn.argtypes = argtypes

@@ -112,6 +112,30 @@ def mini_nested_config(lm_dim: int = 64) -> NestedUNetConfig:
     )
 
 
+def mini_nested2_config(lm_dim: int = 64) -> Nested2UNetConfig:
+    """three levels: a 32-channel conv-only net at 4x resolution around ``mini_nested_config`` whose input is
+    divided by its per-sample std (``skip_normalization=False``, as the middle net of cc12m_1024x1024.yaml:83)."""
+    mid = mini_nested_config(-1)
+    mid.nesting = True
+    mid.skip_normalization = False
+    return Nested2UNetConfig(
+        attention_levels=[],
+        conditioning_feature_dim=lm_dim,
+        conditioning_feature_proj_dim=-1,
+        inner_config=mid,
+        masked_cross_attention=1,
+        micro_conditioning="scale:64",
+        num_attention_layers=[0, 0],
+        num_resnets_per_resolution=[1, 1],
+        resnet_config=ResNetConfig(num_groups_norm=32, dropout=0.0, use_attention_ffn=False),
+        resolution_channels=[32, 32],
+        skip_cond_emb=True,
+        skip_mid_blocks=True,
+        skip_normalization=True,
+        temporal_dim=128,
+    )
+
+
 def _clean(d):
     return {k: (None if v == "None" else v) for k, v in d.items()}
 

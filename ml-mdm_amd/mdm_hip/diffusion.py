@@ -10,6 +10,12 @@ image_side, device, **kw)`` signatures and return tuples, so ``trainer.train_bat
 ``get_loss`` accepts optional ``time`` / ``noise_fn`` overrides so a parity test can feed
 the same timesteps and noise to both implementations (the reference draws them from the
 device RNG, samplers.py:236-241).
+
+Loss-side arithmetic: on GPU tensors the noising ``x_t = sqrt(g) x + sqrt(1-g) eps``
+is one kernel per scale, the image pyramid one ``mdm_avgpool`` per level, and prediction-space conversion + target
++ MSE + per-sample mean one differentiable kernel per scale (``ops.diffusion_loss``) -- 4 launches for the 64x64
+pipeline where the torch formulation needs ~25.  CPU tensors (host-logic tests against the reference goldens) take
+the torch formulation of the same formulas; nothing falls back from the GPU path.
 """
 from dataclasses import dataclass, field
 from typing import List
@@ -19,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import samplers
+from . import ops, samplers
 
 
 @dataclass
@@ -79,6 +85,9 @@ class Diffusion(nn.Module):
         self.model.set_sampler(self.sampler)
         self._config = diffusion_config
         self.loss_fn = nn.MSELoss(reduction="none")
+        # get_loss returns (loss, time, x_t, means, TARGETS, weights) like the reference; the fused GPU loss never
+        # forms the target tensor, so it is built only on request (the trainer of this package does not ask)
+        self.materialize_targets = True
 
     def get_model(self):
         return self.model.module if hasattr(self.model, "module") else self.model
@@ -111,6 +120,16 @@ class Diffusion(nn.Module):
         eps, g, g_last, weights, time = self.sampler.get_eps_time(images, time, noise_fn)
         if not self._config.use_vdm_loss_weights:
             weights = None
+        if images.is_cuda:
+            sc = self._config.sampler_config
+            inv = 1.0 / sc.rescale_signal if sc.rescale_signal else 1.0
+            x_t, eps = ops.noise_images(images.float(), g, eps.float(), inv_scale=inv)
+            means, _ = self.model(x_t, time, lm_outputs, lm_mask, self.get_micro_conditioning(sample))
+            loss = ops.diffusion_loss(means, x_t, images.float(), eps, g, sc.prediction_type, sc.loss_target_type, inv_scale=inv)
+            tgt = None
+            if self.materialize_targets:
+                tgt = self.sampler.get_prediction_targets(self.sampler.get_image_rescaled(images), eps, g, g_last, sc.loss_target_type)
+            return loss, time, x_t, means, tgt, weights
         x_t = self.sampler.get_xt(self.sampler.get_image_rescaled(images), eps, g)
         means, _ = self.model(x_t, time, lm_outputs, lm_mask, self.get_micro_conditioning(sample))
         tgt = self.sampler.get_prediction_targets(images, eps, g, g_last, self._config.sampler_config.loss_target_type)
@@ -151,6 +170,7 @@ class NestedDiffusion(Diffusion):
         self.model.set_sampler(self.sampler)
         self._config = diffusion_config
         self.loss_fn = nn.MSELoss(reduction="none")
+        self.materialize_targets = True
         self.mixed_ratio = None
         if diffusion_config.mixed_ratio:
             r = np.cumsum(np.asarray([float(x) for x in diffusion_config.mixed_ratio.split(":")]))
@@ -169,13 +189,16 @@ class NestedDiffusion(Diffusion):
         if not self._config.use_vdm_loss_weights:
             weights = None
         # image pyramid by average pooling; the low-resolution noise is drawn independently (:333-356)
-        pyr, noises = [images], [eps]
+        hip = images.is_cuda
+        pyr, noises = [images.float() if hip else images], [eps]
         for i in range(1, len(ratios)):
             rr = ratios[i] // ratios[i - 1]
-            pyr.append(F.avg_pool2d(pyr[-1], rr))
+            pyr.append(ops.avgpool(pyr[-1], rr) if hip else F.avg_pool2d(pyr[-1], rr))
             noises.append(noise_fn(pyr[-1]))
         g = self.sampler.get_gammas(g, scales, pyr)
         g_last = self.sampler.get_gammas(g_last, scales, pyr)
+        if hip:
+            return self._get_loss_hip(pyr, noises, g, g_last, scales, time, lm_outputs, lm_mask, micros, weights)
 
         x_t = self.sampler.get_xt(pyr, noises, g, scales)
         p_t = self.model(x_t, time, lm_outputs, lm_mask, micros, self.mixed_ratio)
@@ -198,3 +221,32 @@ class NestedDiffusion(Diffusion):
                 li = pred[i].mean() * 0.0
             loss = loss + li * w[i]
         return loss, time, x_t[0], pred[0], tgt[0], weights
+
+    def _get_loss_hip(self, pyr, noises, g, g_last, scales, time, lm_outputs, lm_mask, micros, weights):
+        """GPU tensors: noising and loss are one kernel each per scale (see the module docstring)"""
+        sc = self._config.sampler_config
+        inv = [1.0 if sc.schedule_shifted else (1.0 / s if s else 1.0) for s in scales]   # NestedSampler._signal
+        x_t = [ops.noise_images(x, gi, e.float(), inv_scale=iv)[0] for x, gi, e, iv in zip(pyr, g, noises, inv)]
+        p_t = self.model(x_t, time, lm_outputs, lm_mask, micros, self.mixed_ratio)
+        if self._config.multi_res_weights is not None:
+            assert self._config.use_double_loss
+            w = [float(v) for v in self._config.multi_res_weights.split(":")]
+        else:
+            w = [1.0] * len(x_t)
+        loss = 0
+        for i in range(len(x_t)):
+            if i == 0 or self._config.use_double_loss:
+                li = ops.diffusion_loss(p_t[i], x_t[i], pyr[i], noises[i].float(), g[i], sc.prediction_type,
+                                        sc.loss_target_type, inv_scale=inv[i])
+                if self.mixed_ratio is not None:
+                    li = li / self.mixed_ratio[i]
+                    li = torch.cat([li[: int(self.mixed_ratio[i] * li.size(0))], li.new_zeros(li.size(0) - int(self.mixed_ratio[i] * li.size(0)))])
+            else:
+                li = p_t[i].mean() * 0.0
+            loss = loss + li * w[i]
+        pred0 = tgt0 = None
+        if self.materialize_targets:
+            tgt0 = samplers.Sampler.get_prediction_targets(self.sampler, self.sampler._signal(pyr[0], scales[0]), noises[0],
+                                                           g[0], g_last[0], sc.loss_target_type)
+            pred0 = self.get_pred_for_training(x_t[0], p_t[0], g[0])
+        return loss, time, x_t[0], pred0, tgt0, weights

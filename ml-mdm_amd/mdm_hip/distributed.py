@@ -44,7 +44,9 @@ def init_distributed_singlenode(timeout: int = 0, backend: str = None):
     (local_rank, global_rank, world_size); a no-op for single-process runs."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 or "MASTER_ADDR" not in os.environ:
-        return 0, 0, 1
+        # single process: still honour LOCAL_RANK / RANK from the environment, as the reference does (:33-40) --
+        # a launcher may pin one process per GPU without a rendezvous
+        return get_local_rank(), int(os.environ.get("RANK", "0")), 1
     rank, local = int(os.environ["RANK"]), get_local_rank()
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -82,6 +84,7 @@ class GradReducer:
         if off > b_start:
             self.buckets.append((b_start, off))
         self._slots = {p.data_ptr(): (p, p.grad) for p in self.params}   # gradient-sink lookup (see ops.set_grad_sink)
+        self._grad_ptrs = [(p, p.grad.data_ptr()) for p in self.params]
         self._need = [0] * len(self.buckets)
         for p in order:
             self._need[self._bucket_of[p]] += 1
@@ -157,8 +160,18 @@ class GradReducer:
 
         return _Ctx()
 
+    def check_bound(self):
+        """``p.grad`` must still be the view into the arena it was created as: ``model.zero_grad()`` /
+        ``optimizer.zero_grad(set_to_none=True)`` silently detach it, after which gradients would neither be
+        all-reduced nor seen by the fused optimizer."""
+        for p, ptr in self._grad_ptrs:
+            if p.grad is None or p.grad.data_ptr() != ptr:
+                raise RuntimeError("a parameter's .grad no longer points into the GradReducer arena (zero_grad(set_to_none=True)?); "
+                                   "use GradReducer.zero_grad()")
+
     def finish(self):
         """join the outstanding all-reduces; afterwards every p.grad holds the rank-average"""
+        self.check_bound()
         if self.world > 1 and self._enabled:
             if self._pending == self._need and not self._work:
                 return  # no synchronised backward since the last finish()

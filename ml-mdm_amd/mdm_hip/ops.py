@@ -108,10 +108,19 @@ def side_stream():
     return _side_stream
 
 
+# Tensors the side stream is still reading.  Holding a reference does two things: the caching allocator cannot hand the
+# block to someone else, and -- the subtle one -- autograd cannot accumulate INTO the tensor in place: a ConvFn /
+# FFNFn backward hands `dy` on as the gradient of its residual input, and the engine's InputBuffer adds a second
+# incoming gradient in place (on the main stream) only when it holds the sole reference to the first.  Entries are
+# dropped once the side-stream event recorded behind their reader has completed, and all at once at the join.
+_side_keep = []
+
+
 def join_side_stream():
     """make the current stream wait for everything queued on the weight-gradient stream"""
     if _side_stream is not None:
         torch.cuda.current_stream().wait_stream(_side_stream)
+    _side_keep.clear()   # every later main-stream write is ordered behind the side stream's reads now
 
 
 def _off_critical_path(tensors, fn):
@@ -122,9 +131,15 @@ def _off_critical_path(tensors, fn):
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         fn()
-    for t in tensors:
-        if t is not None:
-            t.record_stream(side)
+        done = torch.cuda.Event()
+        done.record(side)
+    live = [t for t in tensors if t is not None]
+    for t in live:
+        t.record_stream(side)
+    _side_keep.append((done, live))
+    if len(_side_keep) >= 64:
+        while _side_keep and _side_keep[0][0].query():
+            _side_keep.pop(0)
 
 
 def _cache_slot(weight):
@@ -830,6 +845,198 @@ class MaskedMeanFn(torch.autograd.Function):
 
 def masked_mean(x, mask):
     return MaskedMeanFn.apply(x, mask)
+
+
+# --------------------------------------------------------------------------------------
+# per-pixel arithmetic around the denoiser: NCHW fp32 images (row a7 x / std)
+# --------------------------------------------------------------------------------------
+def _img(t):
+    """fp32, contiguous, on the GPU"""
+    _require_gpu(t)
+    t = t.detach()
+    if t.dtype != torch.float32:
+        raise _lib.MdmHipError("image-side ops take fp32 tensors (got %s)" % t.dtype)
+    return _c(t)
+
+
+def _vec(t, B):
+    """per-sample scalars ([B], [B,1,1,1] ...) -> contiguous fp32 [B] on the GPU"""
+    t = _c(t.detach().reshape(-1).float())
+    if t.numel() != B:
+        raise _lib.MdmHipError("expected %d per-sample values, got %d" % (B, t.numel()))
+    return t
+
+
+class DeviceRng:
+    """{seed, offset} of the library's counter-based normal generator (Philox4x32-10 + Box-Muller), kept ON THE DEVICE so
+    that draws and advances are plain stream work (capturable in a hipGraph).  Element i of a draw is lane i & 3 of
+    counter block offset + i // 4; oracle/philox_ref.py regenerates the same numbers on the host."""
+
+    def __init__(self, seed: int, device, offset: int = 0):
+        self.state = torch.tensor([seed & (2**63 - 1), offset], dtype=torch.int64, device=device)
+
+    def advance(self, n_elements: int):
+        _lib.check(_lib.lib().mdm_rng_advance(_p(self.state), (int(n_elements) + 3) // 4, _stream()), "mdm_rng_advance")
+
+    def randn(self, shape, stream_id: int = 0):
+        out = torch.empty(shape, dtype=torch.float32, device=self.state.device)
+        n = out.numel()
+        if n % 4:
+            raise _lib.MdmHipError("randn: element count must be a multiple of 4")
+        _lib.check(_lib.lib().mdm_randn(_p(out), n, _p(self.state), stream_id, _stream()), "mdm_randn")
+        self.advance(n)
+        return out
+
+
+_PT = {"DDPM": 0, "DDIM": 1, "V_PREDICTION": 2}
+
+
+def _ptype(pt):
+    return _PT[pt.name] if hasattr(pt, "name") else int(pt)
+
+
+def sampler_step(x_t, pred, g, g_last, prediction_type, ddim_eta=None, need_noise=False, noise=None, rng=None,
+                 rng_stream=0, clip="CLIP", image_scale=1.0, pred_uncond=None, guidance_scale=1.0, thr=None,
+                 noise_gate=None):
+    """One reverse-diffusion update (reference samplers.py:281-345 + 445-456 + 500-508) as ONE kernel.
+    -> (x0, x_last).  ``clip``: "NONE" | "CLIP" | "DYNAMIC" (needs ``thr`` [B]) | "X0_ONLY" (returns the unclipped
+    x0 * image_scale and None: the input of the dynamic-threshold quantile)."""
+    x_t, pred = _img(x_t), _img(pred)
+    B = x_t.shape[0]
+    chw = x_t.numel() // B
+    g, gl = _vec(g, B), _vec(g_last, B)
+    pu = _img(pred_uncond) if pred_uncond is not None else None
+    nz = _img(noise) if noise is not None else None
+    th = _vec(thr, B) if thr is not None else None
+    gate = _c(noise_gate.detach().reshape(-1).float()) if noise_gate is not None else None
+    cm = {"NONE": 0, "CLIP": 1, "DYNAMIC": 2, "X0_ONLY": 3}[clip]
+    x0 = torch.empty_like(x_t)
+    xl = torch.empty_like(x_t) if cm != 3 else None
+    mode, eta = (0, 0.0) if ddim_eta is None else (1, float(ddim_eta))
+    gen = bool(need_noise) and nz is None and not (mode == 1 and eta <= 0)
+    if gen and rng is None:
+        raise _lib.MdmHipError("sampler_step: need_noise without noise= or rng=")
+    _lib.check(
+        _lib.lib().mdm_sampler_step(_p(x_t), _p(pred), _p(pu), float(guidance_scale), _p(g), _p(gl), _p(nz), _p(gate), _p(th),
+                                    _p(rng.state) if rng is not None else None, int(rng_stream), _p(x0), _p(xl), B, chw,
+                                    _ptype(prediction_type), mode, eta, 1 if need_noise else 0, cm,
+                                    float(image_scale) if image_scale else 1.0, _stream()),
+        "mdm_sampler_step",
+    )
+    return x0, xl
+
+
+def noise_images(images, g, eps=None, rng=None, rng_stream=0, inv_scale=1.0):
+    """x_t = sqrt(g) * images * inv_scale + sqrt(1 - g) * eps (reference samplers.py:244-246).  ``eps=None`` draws the
+    noise inside the kernel from ``rng``.  -> (x_t, eps)"""
+    images = _img(images)
+    B = images.shape[0]
+    chw = images.numel() // B
+    g = _vec(g, B)
+    x_t = torch.empty_like(images)
+    if eps is None:
+        if rng is None:
+            raise _lib.MdmHipError("noise_images: give eps= or rng=")
+        eps_out = torch.empty_like(images)
+        _lib.check(_lib.lib().mdm_noise_images(_p(images), None, _p(g), float(inv_scale), _p(x_t), _p(eps_out), _p(rng.state),
+                                               int(rng_stream), B, chw, _stream()), "mdm_noise_images")
+        return x_t, eps_out
+    eps = _img(eps)
+    _lib.check(_lib.lib().mdm_noise_images(_p(images), _p(eps), _p(g), float(inv_scale), _p(x_t), None, None, 0, B, chw,
+                                           _stream()), "mdm_noise_images")
+    return x_t, eps
+
+
+class DiffusionLossFn(torch.autograd.Function):
+    """loss[b] = mean_chw (to_target_space(pred; x_t, g) - target(images, eps, g))^2 (reference diffusion.py:144-168
+    with samplers.py:266-279, 347-390 folded in); differentiable w.r.t. ``pred`` only."""
+
+    @staticmethod
+    def forward(ctx, pred, x_t, images, eps, g, inv_scale, ptype, ttype):
+        pred, x_t, images, eps = _img(pred), _img(x_t), _img(images), _img(eps)
+        B = pred.shape[0]
+        chw = pred.numel() // B
+        g = _vec(g, B)
+        wsb = ctypes.c_size_t(0)
+        _lib.check(_lib.lib().mdm_diffusion_loss_plan(B, chw, ctypes.byref(wsb)), "mdm_diffusion_loss_plan")
+        ws = _f32_ws(wsb.value, pred.device)
+        loss = torch.empty(B, dtype=torch.float32, device=pred.device)
+        _lib.check(_lib.lib().mdm_diffusion_loss_fwd(_p(x_t), _p(pred), _p(images), _p(eps), _p(g), float(inv_scale), _p(loss),
+                                                     _p(ws), B, chw, ptype, ttype, _stream()), "mdm_diffusion_loss_fwd")
+        ctx.save_for_backward(pred, x_t, images, eps, g)
+        ctx.cfg = (float(inv_scale), ptype, ttype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred, x_t, images, eps, g = ctx.saved_tensors
+        inv_scale, ptype, ttype = ctx.cfg
+        B = pred.shape[0]
+        chw = pred.numel() // B
+        gl = _vec(gloss, B)
+        dpred = torch.empty_like(pred)
+        _lib.check(_lib.lib().mdm_diffusion_loss_bwd(_p(x_t), _p(pred), _p(images), _p(eps), _p(g), _p(gl), inv_scale, _p(dpred),
+                                                     B, chw, ptype, ttype, _stream()), "mdm_diffusion_loss_bwd")
+        return dpred, None, None, None, None, None, None, None
+
+
+def diffusion_loss(pred, x_t, images, eps, g, prediction_type, target_type, inv_scale=1.0):
+    if pred.dtype != torch.float32:
+        raise _lib.MdmHipError("diffusion_loss: the model output at the boundary is fp32 (got %s)" % pred.dtype)
+    return DiffusionLossFn.apply(pred, x_t, images, eps, g, float(inv_scale), _ptype(prediction_type), _ptype(target_type))
+
+
+def avgpool(x, r):
+    """F.avg_pool2d(x, r) on an NCHW fp32 image batch (the training pyramid, reference diffusion.py:346-348); no gradient"""
+    x = _img(x)
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H // r, W // r), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mdm_avgpool(_p(x), _p(y), N, C, H, W, int(r), _stream()), "mdm_avgpool")
+    return y
+
+
+class SampleStdFn(torch.autograd.Function):
+    """y = x / x.std((1, 2, 3), keepdim=True) (unbiased): the input normalisation of a nested level
+    (reference models/unet.py:871-872)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _img(x)
+        N = x.shape[0]
+        chw = x.numel() // N
+        y = torch.empty_like(x)
+        stats = torch.empty((N, 2), dtype=torch.float32, device=x.device)
+        ws = torch.empty(N * 64 * 2, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mdm_sample_std_fwd(_p(x), _p(y), _p(stats), _p(ws), N, chw, _stream()), "mdm_sample_std_fwd")
+        ctx.save_for_backward(x, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        dy = _c(dy.float())
+        N = x.shape[0]
+        chw = x.numel() // N
+        dx = torch.empty_like(x)
+        ws = torch.empty(N * 64 * 2, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mdm_sample_std_bwd(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), N, chw, _stream()), "mdm_sample_std_bwd")
+        return dx
+
+
+def sample_std_normalize(x):
+    return SampleStdFn.apply(x)
+
+
+def input_stage(u8_nhwc):
+    """uint8 NHWC [B, H, W, 3] -> fp32 NCHW, (u - 127) / 128 (reference clis/train_parallel.py:194-195)"""
+    _require_gpu(u8_nhwc)
+    if u8_nhwc.dtype != torch.uint8 or u8_nhwc.dim() != 4 or u8_nhwc.shape[-1] != 3:
+        raise _lib.MdmHipError("input_stage: expected a uint8 [B, H, W, 3] tensor")
+    u = _c(u8_nhwc)
+    B, H, W, _ = u.shape
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=u.device)
+    _lib.check(_lib.lib().mdm_input_stage(_p(u), _p(out), B, H, W, _stream()), "mdm_input_stage")
+    return out
 
 
 # --------------------------------------------------------------------------------------

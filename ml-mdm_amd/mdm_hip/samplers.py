@@ -3,11 +3,16 @@
 Host-side mirror of ``ml_mdm.samplers`` (reference ml-mdm-matryoshka/ml_mdm/samplers.py):
 ``SamplerConfig`` (:67-118), the schedule families (:126-165), ``Sampler`` (:177-609) and
 ``NestedSampler`` (:612-793) with the same public method names, so the reference's
-``Diffusion`` / CLIs can drive it.  This is caller-side glue, not the hot path: the
-per-pixel arithmetic here is a handful of elementwise torch ops on [B, 3, H, W] images
-(SURVEY.md section 8f row N1 lists fusing them as the next step).  One deliberate
-difference: gammas are carried as per-sample ``[B, 1, 1, 1]`` tensors and broadcast,
-instead of being materialised at full image size (:196-199).
+``Diffusion`` / CLIs can drive it.
+
+Per-pixel arithmetic: on GPU tensors one reverse step --
+guidance combine, v/eps -> x0, clip / dynamic threshold, DDPM posterior or DDIM(eta)
+update, noise -- is ONE kernel per scale (``ops.sampler_step`` -> ``mdm_sampler_step``);
+there is no fallback from that path (a missing library raises).  The same formulas written
+with torch ops serve CPU tensors: that is what the host-logic tests drive against the
+reference's golden outputs (tests/test_diffusion_host.py), and what a custom ``clip_fn``
+gets.  One deliberate difference from the reference: gammas are per-sample ``[B, 1, 1, 1]``
+tensors, broadcast, instead of being materialised at full image size (:196-199).
 """
 import math
 from dataclasses import dataclass
@@ -17,6 +22,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import ops
 
 
 class ScheduleType(Enum):
@@ -113,6 +120,13 @@ class Sampler(nn.Module):
         self.register_buffer("vdm_loss_weights", torch.cat([w[:1], w[:1], w]))
         if cfg.loss_target_type is None:
             cfg.loss_target_type = cfg.prediction_type
+        self.device_rng = None   # ops.DeviceRng: draw the sampling noise inside the step kernel (see use_device_rng)
+
+    def use_device_rng(self, seed: int, device):
+        """Draw the ancestral-sampling noise INSIDE the step kernel from the library's counter-based generator
+        (replayable on the host, oracle/philox_ref.py) instead of ``torch.randn_like`` -- one launch less per scale."""
+        self.device_rng = ops.DeviceRng(seed, device)
+        return self
 
     # ---- schedule access -------------------------------------------------------------
     def read_gamma(self, time, image=None):
@@ -174,7 +188,13 @@ class Sampler(nn.Module):
 
     # ---- one reverse step (:281-345) -------------------------------------------------------
     def get_prediction_xt_last(self, x_t, pred, g, g_last, prediction_type=None, clip_fn=None, need_noise=False,
-                               ddim_eta=None, input_noise=None, image_scale=None):
+                               ddim_eta=None, input_noise=None, image_scale=None, return_eps=True, pred_uncond=None,
+                               guidance_scale=1):
+        if x_t.is_cuda and (clip_fn is None or clip_fn == self.clip_sample):
+            return self._xt_last_hip(x_t, pred, g, g_last, prediction_type, clip_fn is not None, need_noise, ddim_eta,
+                                     input_noise, image_scale, return_eps, pred_uncond, guidance_scale)
+        if pred_uncond is not None:
+            pred = pred_uncond + guidance_scale * (pred - pred_uncond)
         alpha = g / g_last
         beta = 1 - alpha
         beta_tilde = beta * (1 - g_last) / (1 - g)
@@ -194,7 +214,40 @@ class Sampler(nn.Module):
         if need_noise:
             noise = torch.randn_like(x_last) if input_noise is None else input_noise
             x_last = x_last + beta_tilde.sqrt() * noise
-        eps = (x_last - g_last.sqrt() * x0) / (1 - g_last).sqrt()
+        eps = (x_last - g_last.sqrt() * x0) / (1 - g_last).sqrt() if return_eps else None
+        return x0, x_last, eps
+
+    def _xt_last_hip(self, x_t, pred, g, g_last, prediction_type, use_clip_sample, need_noise, ddim_eta, input_noise,
+                     image_scale, return_eps, pred_uncond, guidance_scale):
+        """the same update as ONE kernel (two for dynamic thresholding: the quantile sits between them)"""
+        pt = prediction_type or self._config.prediction_type
+        scale = 1 if image_scale is None else image_scale
+        x_t, pred = x_t.float(), pred.float()
+        kw = dict(prediction_type=pt, ddim_eta=ddim_eta, image_scale=scale, guidance_scale=guidance_scale,
+                  pred_uncond=None if pred_uncond is None else pred_uncond.float())
+        fn = self._config.threshold_function if use_clip_sample else None
+        thr, clip = None, "NONE"
+        if fn in (ThresholdType.DYNAMIC, ThresholdType.DYNAMIC_IF):
+            ratio, vmax = (0.995, 100) if fn == ThresholdType.DYNAMIC else (0.95, 1.5)
+            x0s, _ = ops.sampler_step(x_t, pred, g, g_last, clip="X0_ONLY", **kw)
+            thr = torch.quantile(x0s.reshape(x0s.shape[0], -1).abs(), ratio, dim=1).clamp(min=1, max=vmax)
+            clip = "DYNAMIC"
+        elif fn == ThresholdType.CLIP:
+            clip = "CLIP"
+        elif not use_clip_sample:
+            # clip_fn=None in the reference: clamp(x0, -s, s) / s == CLIP on x0 / s with unit scale ... only for s == 1
+            if scale != 1:
+                raise NotImplementedError("clip_fn=None with image_scale != 1 on the HIP path")
+            clip = "CLIP"
+        noisy = need_noise and not (ddim_eta is not None and ddim_eta <= 0)
+        noise = input_noise
+        if noisy and noise is None and self.device_rng is None:
+            noise = torch.randn_like(x_t)   # torch's generator, like the reference (:340)
+        x0, x_last = ops.sampler_step(x_t, pred, g, g_last, need_noise=noisy, noise=noise, rng=self.device_rng, clip=clip,
+                                      thr=thr, **kw)
+        if noisy and noise is None:
+            self.device_rng.advance(x_t.numel())
+        eps = (x_last - _b(g_last).sqrt() * x0) / (1 - _b(g_last)).sqrt() if return_eps else None
         return x0, x_last, eps
 
     def _threshold_sample(self, sample, ratio=0.995, max_value=100):
@@ -216,12 +269,19 @@ class Sampler(nn.Module):
 
     def forward_model(self, model, x_t, t, lm_outputs, lm_mask, micros={}, guidance_scale=1):
         """classifier-free guidance doubles the batch: [uncond | cond] (:435-459)."""
+        pc, pu, extras = self._forward_model_raw(model, x_t, t, lm_outputs, lm_mask, micros, guidance_scale)
+        return (pc if pu is None else pu + guidance_scale * (pc - pu)), extras
+
+    def _forward_model_raw(self, model, x_t, t, lm_outputs, lm_mask, micros, guidance_scale):
+        """-> (conditional prediction, unconditional prediction or None, extras): the guidance combine itself is
+        folded into the step kernel"""
         if guidance_scale != 1:
             assert x_t.shape[0] * 2 == lm_outputs.shape[0]
             pred, extras = model(torch.cat([x_t] * 2), torch.cat([t, t]), lm_outputs, lm_mask, micros=micros)
             pu, pc = pred.chunk(2)
-            return pu + guidance_scale * (pc - pu), extras.chunk(2)[1]
-        return model(x_t, t, lm_outputs, lm_mask, micros)
+            return pc, pu, extras.chunk(2)[1]
+        pred, extras = model(x_t, t, lm_outputs, lm_mask, micros)
+        return pred, None, extras
 
     def get_xt_minus_1(self, model, time_step, x_t, lm_outputs, lm_mask, micros={}, time_step_last=None,
                        guidance_scale=1, ddim_eta=None, return_details=False):
@@ -229,10 +289,11 @@ class Sampler(nn.Module):
         last = time_step - 1 if time_step_last is None else time_step_last
         t, s = ones * time_step, ones * last
         g, g_last = self.read_gamma(t), self.read_gamma(s)
-        pred, _ = self.forward_model(model, x_t, t - 1, lm_outputs, lm_mask, micros, guidance_scale)  # model sees t-1 (:415)
+        pc, pu, _ = self._forward_model_raw(model, x_t, t - 1, lm_outputs, lm_mask, micros, guidance_scale)  # model sees t-1 (:415)
         x0, x_s, _ = self.get_prediction_xt_last(
-            x_t, pred, g, g_last, prediction_type=self._config.prediction_type, need_noise=(last != 0),
-            ddim_eta=ddim_eta, clip_fn=self.clip_sample, image_scale=self._config.rescale_signal)
+            x_t, pc, g, g_last, prediction_type=self._config.prediction_type, need_noise=bool(last != 0),
+            ddim_eta=ddim_eta, clip_fn=self.clip_sample, image_scale=self._config.rescale_signal, return_eps=False,
+            pred_uncond=pu, guidance_scale=guidance_scale)
         return (x0, x_s, (g, g_last)) if return_details else x_s
 
     # ---- the sampling loop (:510-609) ----------------------------------------------------------
@@ -298,15 +359,18 @@ class NestedSampler(Sampler):
                 for x, s, e, gi, gl in zip(x0, scales, eps, g, g_last)]
 
     def forward_model(self, model, x_t, t, lm_outputs, lm_mask, micros={}, guidance_scale=1):
+        pcs, pus = self._forward_model_raw(model, x_t, t, lm_outputs, lm_mask, micros, guidance_scale)
+        return [pc if pu is None else pu + guidance_scale * (pc - pu) for pc, pu in zip(pcs, pus)]
+
+    def _forward_model_raw(self, model, x_t, t, lm_outputs, lm_mask, micros, guidance_scale):
+        """-> (conditional predictions, unconditional predictions or Nones), one entry per scale (:777-790)"""
         if guidance_scale != 1:
             assert x_t[0].shape[0] * 2 == lm_outputs.shape[0]
             p_t = model([torch.cat([x] * 2) for x in x_t], torch.cat([t] * 2), lm_outputs, lm_mask, micros)
-            out = []
-            for p in p_t:
-                pu, pc = p.chunk(2)
-                out.append(pu + guidance_scale * (pc - pu))
-            return out
-        return model(x_t, t, lm_outputs, lm_mask, micros)
+            halves = [p.chunk(2) for p in p_t]
+            return [h[1] for h in halves], [h[0] for h in halves]
+        p_t = model(x_t, t, lm_outputs, lm_mask, micros)
+        return list(p_t), [None] * len(p_t)
 
     def get_xt_minus_1(self, model, time_step, x_t, lm_outputs, lm_mask, micros={}, time_step_last=None,
                        guidance_scale=1, ddim_eta=None, return_details=False):
@@ -322,12 +386,13 @@ class NestedSampler(Sampler):
         s = t - 1 if time_step_last is None else ones * time_step_last
         g_t = self.get_gammas(self.read_gamma(t), scales)
         g_s = self.get_gammas(self.read_gamma(s), scales)
-        p_t = self.forward_model(model, x_t, t - 1, lm_outputs, lm_mask, micros, guidance_scale)
+        pcs, pus = self._forward_model_raw(model, x_t, t - 1, lm_outputs, lm_mask, micros, guidance_scale)
         x0, x_s = [], []
-        for x, p, g, gl, sc in zip(x_t, p_t, g_t, g_s, scales):
+        for x, pc, pu, g, gl, sc in zip(x_t, pcs, pus, g_t, g_s, scales):
             a, b, _ = self.get_prediction_xt_last(
-                x, p, g, gl, prediction_type=self._config.prediction_type, need_noise=time_step != 1,
-                ddim_eta=ddim_eta, clip_fn=self.clip_sample, image_scale=sc if not self._config.schedule_shifted else 1)
+                x, pc, g, gl, prediction_type=self._config.prediction_type, need_noise=bool(time_step != 1),
+                ddim_eta=ddim_eta, clip_fn=self.clip_sample, image_scale=sc if not self._config.schedule_shifted else 1,
+                return_eps=False, pred_uncond=pu, guidance_scale=guidance_scale)
             x0.append(a)
             x_s.append(b)
         return (x0, x_s, (g_t[-1], g_s[-1])) if return_details else x_s

@@ -8,7 +8,7 @@ buffers).  bf16 needs no loss scaling, so the reference's GradScaler is not repr
 On the GPU the optimizer tail is fused: gradients land directly in a flat arena
 and ``mdm_sumsq`` + ``mdm_adamw_ema_step`` do clip + AdamW + EMA + zero-grad in two streaming passes.
 """
-import os
+import math
 
 import torch
 
@@ -23,7 +23,8 @@ class TrainStep:
     optimizer (CPU tests, or as a cross-check)."""
 
     def __init__(self, pipeline, lr=5e-5, clip_norm=2.0, ema_decay=0.9999, bf16=True, use_ema=True,
-                 bucket_mb=256.0, wire_dtype=None, fused=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+                 bucket_mb=256.0, wire_dtype=None, fused=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 async_wgrad=True):
         self.pipeline = pipeline
         self.net = pipeline.get_model().vision_model
         self.params = [p for p in self.net.parameters() if p.requires_grad]
@@ -33,7 +34,8 @@ class TrainStep:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.clip_norm, self.bf16, self.ema_decay = clip_norm, bf16, ema_decay
         self.steps = 0
-        self._hi = None
+        if self.fused:
+            pipeline.materialize_targets = False   # the fused loss kernel never forms the target tensor; nobody reads it here
         if self.fused:
             # flat parameter arena in the SAME order as the gradient arena (reverse registration order)
             flat = torch.empty_like(self.reducer.flat)
@@ -51,8 +53,7 @@ class TrainStep:
             self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
             self.reducer.rebind()
             ops.set_grad_sink(self.reducer)
-            ops.enable_async_wgrad(os.environ.get("MDM_HIP_ASYNC_WGRAD", "1") != "0")
-            self._hi = torch.cuda.Stream(priority=-1) if os.environ.get("MDM_HIP_HIPRIO", "0") != "0" else None   # measured: no effect (137.8 vs 137.4 ms)
+            ops.enable_async_wgrad(async_wgrad)
             ops.invalidate_packed_weights()
             self.opt = None
             self.ema = None
@@ -72,24 +73,20 @@ class TrainStep:
         return {names[id(p)]: e for p, e in zip(self.params, self.ema)}
 
     def __call__(self, sample, **loss_kw):
-        if self.fused and self._hi is not None:
-            # critical chain on a high-priority stream: its many small kernels must not queue behind the big
-            # weight-gradient grids of the side stream
-            self._hi.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._hi):
-                out = self._step(sample, **loss_kw)
-            torch.cuda.current_stream().wait_stream(self._hi)
-            return out
-        return self._step(sample, **loss_kw)
-
-    def _step(self, sample, **loss_kw):
         self.pipeline.train()
         dev_type = "cuda" if self.params[0].is_cuda else "cpu"
         with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=self.bf16):
             losses, times, x_t, means, targets, weights = self.pipeline.get_loss(sample, **loss_kw)
             loss = losses.mean() if weights is None else (losses * weights).sum() / weights.sum()
         loss_val = loss.item()  # the reference syncs here every step (trainer.py:37)
-        if loss_val != loss_val:
+        bad = not math.isfinite(loss_val)
+        if self.reducer.world > 1:
+            # every rank must take the same branch, or the ranks that run backward wait for bucket all-reduces the
+            # skipping rank never issues (the reference's DDP hangs the same way: trainer.py:38-41 returns per rank)
+            flag = torch.tensor([1.0 if bad else 0.0], device=self.params[0].device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=self.reducer.group)
+            bad = bool(flag.item() > 0)
+        if bad:
             self.reducer.zero_grad()
             return loss_val
         loss.backward()

@@ -396,8 +396,8 @@ class UNet(nn.Module):
     def forward_input_layer(self, x_t, normalize=False):
         if isinstance(x_t, (list, tuple)) and len(x_t) == 1:
             x_t = x_t[0]
-        if normalize:
-            x_t = x_t / x_t.std((1, 2, 3), keepdims=True)
+        if normalize:   # per-sample x / std (reference :871-872), its own kernel pair
+            x_t = ops.sample_std_normalize(x_t.float())
         return ops.conv(ops.to_nhwc(x_t, compute_dtype()), self.conv_in.weight, self.conv_in.bias)
 
     def forward_output_layer(self, x):

@@ -174,7 +174,71 @@ def sampling_golden():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def full_size_golden():
+    """The three SHIPPED architectures at full size through the REAL reference (CPU fp32):
+      unet64     (BASELINE.json configs[0]/[1]): forward B=2 + every parameter-gradient norm / probe, and the configs[0]
+                 pipeline: Diffusion.sample() 4 DDIM steps at batch 2 + get_loss() on seeded inputs
+      nested256  (configs[2]/[3]): forward + gradients, B=1
+      nested1024 (configs[4]): forward B=1 (includes the x / std input normalisation of the 256 level)
+    Outputs are kept as summaries (norm, seeded probe, strided subsample): the 1024^2 output alone is 12.6 MB."""
+    import time
+
+    R = ref_import.load()
+    S, D = R.samplers, R.diffusion
+    blob = {"torch": torch.__version__}
+    for name in PC.FULL:
+        t0 = time.time()
+        _, sd = PC.full_module(name)
+        rcfg = to_ref_cfg(R, PC.full_cfg(name))
+        nested = hasattr(rcfg, "inner_config")
+        ref = (R.nested_unet.NestedUNet if nested else R.unet.UNet)(3, 3, rcfg)
+        ref.load_state_dict(sd, strict=True)
+        inp = PC.full_inputs(name)
+        with_grad = name != "nested1024"
+        ent = {"param_sum": {k: float(v.double().sum()) for k, v in list(sd.items())[::37]}}
+        if with_grad:
+            outs = PC.as_list(ref(inp["x"], inp["times"], inp["cond"], inp["mask"]))
+            PC.loss_of(outs, inp["gys"]).backward()
+            grads = {k: p.grad for k, p in ref.named_parameters()}
+            ent["grad_norm"] = {k: float(g.double().norm()) for k, g in grads.items()}
+            ent["grad_probe"] = {k: float((g.double() * PC.probe_for(k, g.shape)).sum()) for k, g in grads.items()}
+            ref.zero_grad(set_to_none=True)
+        else:
+            with torch.no_grad():
+                outs = PC.as_list(ref(inp["x"], inp["times"], inp["cond"], inp["mask"]))
+        ent["outputs"] = [PC.summarize_output(o, "%s.out%d" % (name, i)) for i, o in enumerate(outs)]
+        if name == "unet64":
+            # BASELINE.json configs[0]: cc12m_64x64, batch 2, 4 diffusion steps, random T5 embeddings, CPU reference
+            scfg = S.SamplerConfig(num_diffusion_steps=1000, schedule_type=S.ScheduleType.DEEPFLOYD,
+                                   prediction_type=S.PredictionType.V_PREDICTION, loss_target_type=S.PredictionType.DDPM,
+                                   threshold_function=S.ThresholdType.CLIP)
+            pipe = D.Diffusion(ref, D.DiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False))
+            smp = {"lm_outputs": inp["cond"], "lm_mask": inp["mask"]}
+            torch.manual_seed(23)
+            with torch.no_grad():
+                img = pipe.sample(2, smp, 64, torch.device("cpu"), resample_steps=True, num_inference_steps=4, ddim_eta=0)
+            g = torch.Generator().manual_seed(29)
+            smp["images"] = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+            torch.manual_seed(31)
+            pipe.train()
+            loss = pipe.get_loss(smp)[0]
+            ent["sample"] = img.detach().clone()
+            ent["loss"] = loss.detach().clone()
+        blob[name] = ent
+        print(name, "done in %.1f s; out norms" % (time.time() - t0), [o["norm"] for o in ent["outputs"]])
+        del ref
+    path = os.path.join(ROOT, "tests", "golden", "full_size.pt")
+    torch.save(blob, path)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
-    diffusion_host_golden()
-    sampling_golden()
+    which = sys.argv[1:] or ["mini", "host", "pipeline", "full"]
+    if "mini" in which:
+        main()
+    if "host" in which:
+        diffusion_host_golden()
+    if "pipeline" in which:
+        sampling_golden()
+    if "full" in which:
+        full_size_golden()

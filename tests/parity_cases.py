@@ -18,10 +18,14 @@ def _cfg(name):
         "mini_unet": configs.mini_unet_config,
         "mini_unet_masked": lambda: configs.mini_unet_config(masked=1),
         "mini_nested": configs.mini_nested_config,
+        "mini_nested2": configs.mini_nested2_config,
     }[name]()
 
 
-CASES = ["mini_unet", "mini_unet_masked", "mini_nested"]
+# mini_nested2: three nesting levels (64 + 32 + 16) whose middle net normalises its input by the per-sample std
+# (skip_normalization=False) -- the topology of the reference's cc12m_1024x1024.yaml at test size
+CASES = ["mini_unet", "mini_unet_masked", "mini_nested", "mini_nested2"]
+_SIDES = {"mini_unet": [16], "mini_unet_masked": [16], "mini_nested": [32, 16], "mini_nested2": [64, 32, 16]}
 
 
 def build_module(name, seed=0):
@@ -45,13 +49,12 @@ def inputs(name, seed=1):
     mask[1, 5:] = 0
     cond = cond * mask.unsqueeze(-1)
     times = torch.tensor([3, 977])
-    side = 32 if name == "mini_nested" else 16
-    if name == "mini_nested":
-        x = [torch.randn(B, 3, side, side, generator=g), torch.randn(B, 3, side // 2, side // 2, generator=g)]
-    else:
-        x = torch.randn(B, 3, side, side, generator=g)
-    outs = [(B, 3, side, side)] + ([(B, 3, side // 2, side // 2)] if name == "mini_nested" else [])
-    gys = [torch.randn(s, generator=g) for s in outs]
+    sides = _SIDES[name]
+    xs = [torch.randn(B, 3, sd, sd, generator=g) for sd in sides]
+    if name == "mini_nested2":
+        xs[1] = xs[1] * 1.7 + 0.3   # make the std-normalisation of the middle level visible (std != 1, mean != 0)
+    x = xs if len(sides) > 1 else xs[0]
+    gys = [torch.randn(B, 3, sd, sd, generator=g) for sd in sides]
     return dict(x=x, times=times, cond=cond, mask=mask, gys=gys)
 
 
@@ -101,3 +104,66 @@ def grad_errors(grads, g_ref, floor_frac=1e-2):
         d = float((grads[k].detach().double().cpu() - r.double()).norm())
         errs[k] = d / max(float(r.double().norm()), floor)
     return errs, floor
+
+
+# ---------------------------------------------------------------------------------------------------------
+# FULL-SIZE cases: the three architectures the reference ships (BASELINE.json configs[0..4]), seeded weights
+# (reference init + seeded randomisation of the zero-initialised tensors), seeded inputs.
+# ---------------------------------------------------------------------------------------------------------
+FULL = {
+    # name: (config constructor, sides hi->lo, batch)
+    "unet64": ("unet64_config", [64], 2),
+    "nested256": ("nested256_config", [256, 64], 1),
+    "nested1024": ("nested1024_config", [1024, 256, 64], 1),
+}
+
+
+def full_cfg(name):
+    from mdm_hip import configs
+
+    return getattr(configs, FULL[name][0])(2048)
+
+
+def full_module(name, seed=0, param_seed=99):
+    """our module at full size with the case's parameters (CPU); -> (module, state_dict)"""
+    import mdm_hip
+
+    cfg = full_cfg(name)
+    cls = mdm_hip.NestedUNet if hasattr(cfg, "inner_config") else mdm_hip.UNet
+    torch.manual_seed(seed)
+    model = cls(3, 3, cfg)
+    sd = O.randomize_zero_params(model.state_dict(), seed=param_seed)
+    model.load_state_dict(sd)
+    return model, sd
+
+
+def full_inputs(name, seed=5):
+    _, sides, B = FULL[name]
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn(B, 3, sd, sd, generator=g) for sd in sides]
+    if name == "nested1024":
+        xs[1] = xs[1] * 1.7 + 0.3          # the 256-level input is divided by its std (cc12m_1024x1024.yaml:83)
+    cond = torch.randn(B, 32, 2048, generator=g)
+    mask = torch.ones(B, 32)
+    times = torch.tensor([417, 88, 903, 12][:B])
+    gys = [torch.randn(B, 3, sd, sd, generator=g) for sd in sides]
+    return dict(x=xs if len(sides) > 1 else xs[0], times=times, cond=cond, mask=mask, gys=gys)
+
+
+def summarize_output(t, key):
+    """what the golden files keep of a (possibly 12 MB) output tensor: norm, a seeded probe, a strided subsample"""
+    t = t.detach().double()
+    st = max(1, t.shape[-1] // 64)
+    return {"norm": float(t.norm()), "probe": float((t * probe_for(key, t.shape)).sum()),
+            "sub": t[..., ::st, ::st].float().clone()}
+
+
+def check_summary(t, gold, key, tol):
+    """|| t - ref || / || ref || < tol, through the summary a golden file holds for ref"""
+    t = t.detach().double().cpu()
+    st = max(1, t.shape[-1] // 64)
+    n = gold["norm"]
+    assert abs(float(t.norm()) - n) <= tol * n, (key, float(t.norm()), n)
+    # a probe is a unit-variance random projection: |<t - ref, probe>| ~ ||t - ref||
+    assert abs(float((t * probe_for(key, t.shape)).sum()) - gold["probe"]) <= 4 * tol * n, key
+    assert O.rel_l2(t[..., ::st, ::st], gold["sub"]) < tol, key

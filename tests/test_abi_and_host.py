@@ -144,3 +144,19 @@ def test_module_is_deepcopyable_and_checkpoint_roundtrips(tmp_path):
     rest = fresh.load(f)
     assert rest["batch_num"] == 7
     assert all(torch.equal(v, sd[k]) for k, v in fresh.state_dict().items())
+
+
+def test_philox_reference_known_answers():
+    """oracle/philox_ref.py (the host replay of the device noise generator) against the published Philox4x32-10
+    known-answer vectors of the Random123 distribution (kat_vectors: counter / key all zero, all ones, pi digits)"""
+    import philox_ref as P
+
+    def run(c, k):
+        return [int(x[0]) for x in P.philox4x32_10([c[0]], [c[1]], [c[2]], [c[3]], k[0], k[1])]
+
+    assert run((0, 0, 0, 0), (0, 0)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    f = 0xFFFFFFFF
+    assert run((f, f, f, f), (f, f)) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert run((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    z = P.normals(1 << 18, seed=42)
+    assert abs(float(z.mean())) < 1e-2 and abs(float(z.std()) - 1.0) < 1e-2

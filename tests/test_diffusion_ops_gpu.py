@@ -1,0 +1,199 @@
+"""GPU: the per-pixel kernels around the denoiser (SURVEY.md section 8f rows N1, N3, N4 and the x / std of row a7),
+called through the C ABI, against the torch fp32 formulation of the reference's formulas (the CPU path of
+mdm_hip.samplers / mdm_hip.diffusion, itself pinned to the real reference by tests/test_diffusion_host.py) and against
+the host replay of the device RNG (oracle/philox_ref.py).  All fp32: tolerance 2e-6 relative to the largest value."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def _sampler(pred="V_PREDICTION", thr="CLIP", **kw):
+    from mdm_hip import samplers as S
+
+    return S.Sampler(S.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type=pred,
+                                     loss_target_type="DDPM", threshold_function=thr, **kw))
+
+
+@pytest.mark.parametrize("pred", ["V_PREDICTION", "DDPM"])
+@pytest.mark.parametrize("thr", ["CLIP", "DYNAMIC", "NONE"])
+@pytest.mark.parametrize("eta,noisy", [(None, True), (None, False), (0.0, True), (0.6, True), (1.0, True)])
+@pytest.mark.parametrize("cfg,scale", [(1.0, None), (3.0, 2.0)])
+def test_sampler_step_matches_reference_formulas(pred, thr, eta, noisy, cfg, scale):
+    """Sampler.get_prediction_xt_last on GPU tensors (one mdm_sampler_step launch, guidance combine folded in) ==
+    the same method on CPU tensors (the torch restatement of samplers.py:281-345 pinned by the host goldens)."""
+    smp = _sampler(pred, thr)
+    g = torch.Generator().manual_seed(3)
+    B, H = 3, 20
+    x_t = torch.randn(B, 3, H, H, generator=g) * 1.3
+    pc, pu = torch.randn(B, 3, H, H, generator=g), torch.randn(B, 3, H, H, generator=g)
+    noise = torch.randn(B, 3, H, H, generator=g)
+    t = torch.tensor([700, 31, 999])
+    gam, gl = smp.read_gamma(t), smp.read_gamma(t - torch.tensor([40, 30, 99]))
+    kw = dict(prediction_type=smp._config.prediction_type, need_noise=noisy, ddim_eta=eta, image_scale=scale,
+              guidance_scale=cfg)
+    ref = smp.get_prediction_xt_last(x_t, pc, gam, gl, clip_fn=smp.clip_sample, input_noise=noise,
+                                     pred_uncond=pu if cfg != 1 else None, **kw)
+    smp_d = _sampler(pred, thr).to(DEV)
+    out = smp_d.get_prediction_xt_last(x_t.to(DEV), pc.to(DEV), gam.to(DEV), gl.to(DEV), clip_fn=smp_d.clip_sample,
+                                       input_noise=noise.to(DEV), pred_uncond=pu.to(DEV) if cfg != 1 else None, **kw)
+    for a, b in zip(out, ref):
+        assert relerr(a, b) < 5e-6
+
+
+def test_device_rng_is_replayable_on_the_host():
+    import philox_ref as P
+    from mdm_hip import ops
+
+    rng = ops.DeviceRng(seed=0x1234_5678_9ABC, device=DEV)
+    a = rng.randn((2, 3, 16, 16), stream_id=0)
+    b = rng.randn((4, 8), stream_id=5)
+    ra = P.normals(a.numel(), 0x1234_5678_9ABC, 0, 0).reshape(a.shape)
+    rb = P.normals(b.numel(), 0x1234_5678_9ABC, a.numel() // 4, 5).reshape(b.shape)
+    assert np.abs(a.cpu().numpy() - ra).max() < 2e-5 and np.abs(b.cpu().numpy() - rb).max() < 2e-5
+    assert int(rng.state[1].item()) == (a.numel() + b.numel()) // 4
+    big = rng.randn((1 << 20,))
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1) < 5e-3
+
+
+def test_in_kernel_noise_of_the_sampler_step():
+    """need_noise with the device generator: x_last == the injected-noise result for the host-replayed draw"""
+    import philox_ref as P
+    from mdm_hip import ops
+
+    smp = _sampler().to(DEV)
+    g = torch.Generator().manual_seed(4)
+    x_t, pr = torch.randn(2, 3, 16, 16, generator=g).to(DEV), torch.randn(2, 3, 16, 16, generator=g).to(DEV)
+    t = torch.tensor([500, 80], device=DEV)
+    gam, gl = smp.read_gamma(t), smp.read_gamma(t - 20)
+    rng = ops.DeviceRng(77, DEV, offset=5)
+    _, xl = ops.sampler_step(x_t, pr, gam, gl, smp._config.prediction_type, need_noise=True, rng=rng, rng_stream=2)
+    nz = torch.from_numpy(P.normals(x_t.numel(), 77, 5, 2).reshape(x_t.shape)).to(DEV)
+    _, xr = ops.sampler_step(x_t, pr, gam, gl, smp._config.prediction_type, need_noise=True, noise=nz)
+    assert relerr(xl, xr) < 1e-5
+
+
+@pytest.mark.parametrize("pt,tt", [("V_PREDICTION", "DDPM"), ("DDPM", "V_PREDICTION"), ("DDPM", "DDPM"), ("V_PREDICTION", "V_PREDICTION")])
+@pytest.mark.parametrize("rescale", [None, 2.0])
+def test_noising_and_loss_kernels(pt, tt, rescale):
+    """mdm_noise_images + mdm_diffusion_loss_fwd/bwd == get_xt / get_prediction_targets / get_pred_for_training / MSE in
+    torch (diffusion.py:144-168), loss and gradient w.r.t. the model output"""
+    from mdm_hip import ops
+    from mdm_hip import samplers as S
+
+    smp = S.Sampler(S.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type=pt,
+                                    loss_target_type=tt, rescale_signal=rescale))
+    cfg = smp._config
+    g = torch.Generator().manual_seed(8)
+    B, H = 5, 24
+    img, eps = torch.rand(B, 3, H, H, generator=g) * 2 - 1, torch.randn(B, 3, H, H, generator=g)
+    pred = torch.randn(B, 3, H, H, generator=g).requires_grad_()
+    gam = smp.read_gamma(torch.tensor([1, 200, 555, 900, 1000]))
+    x_ref = smp.get_xt(smp.get_image_rescaled(img), eps, gam)
+    tgt = smp.get_prediction_targets(smp.get_image_rescaled(img), eps, gam, gam, cfg.loss_target_type)
+    p = pred
+    if cfg.loss_target_type != cfg.prediction_type:
+        x0, _ = smp.get_x0_eps_from_pred(x_ref, pred, gam, cfg.prediction_type)
+        p = smp.get_pred_from_x0_xt(x_ref, x0, gam, cfg.loss_target_type)
+    loss_ref = F.mse_loss(p, tgt, reduction="none").mean(dim=(1, 2, 3))
+    wts = torch.tensor([0.3, 1.0, 2.0, 0.5, 1.5])
+    (loss_ref * wts).sum().backward()
+    inv = 1.0 / rescale if rescale else 1.0
+    x_d, _ = ops.noise_images(img.to(DEV), gam.to(DEV), eps.to(DEV), inv_scale=inv)
+    assert relerr(x_d, x_ref) < 2e-6
+    pd = pred.detach().to(DEV).requires_grad_()
+    loss = ops.diffusion_loss(pd, x_d, img.to(DEV), eps.to(DEV), gam.to(DEV), cfg.prediction_type, cfg.loss_target_type, inv_scale=inv)
+    (loss * wts.to(DEV)).sum().backward()
+    assert relerr(loss, loss_ref) < 1e-5
+    assert relerr(pd.grad, pred.grad) < 1e-5
+
+
+def test_noise_images_draws_replayable_noise():
+    import philox_ref as P
+    from mdm_hip import ops
+
+    img = torch.rand(2, 3, 8, 8).to(DEV)
+    gam = torch.tensor([0.7, 0.2], device=DEV)
+    rng = ops.DeviceRng(9, DEV)
+    x_t, eps = ops.noise_images(img, gam, rng=rng, rng_stream=1)
+    ref = torch.from_numpy(P.normals(img.numel(), 9, 0, 1).reshape(img.shape)).to(DEV)
+    assert relerr(eps, ref) < 2e-5
+    assert relerr(x_t, gam.sqrt().view(-1, 1, 1, 1) * img + (1 - gam).sqrt().view(-1, 1, 1, 1) * eps) < 2e-6
+
+
+@pytest.mark.parametrize("N,C,H,W,r", [(2, 3, 64, 64, 4), (3, 3, 32, 48, 2), (1, 3, 256, 256, 4), (2, 5, 12, 12, 1)])
+def test_avgpool(N, C, H, W, r):
+    from mdm_hip import ops
+
+    x = torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(1))
+    assert relerr(ops.avgpool(x.to(DEV), r), F.avg_pool2d(x, r)) < 2e-6
+
+
+@pytest.mark.parametrize("N,H", [(2, 32), (3, 256), (1, 10)])
+def test_sample_std_normalisation(N, H):
+    """x / x.std((1,2,3)) (models/unet.py:871-872) and its gradient"""
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(N, 3, H, H, generator=g) * 2.3 + 0.7).requires_grad_()
+    y_ref = x / x.std((1, 2, 3), keepdim=True)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd = x.detach().to(DEV).requires_grad_()
+    y = ops.sample_std_normalize(xd)
+    y.backward(gy.to(DEV))
+    assert relerr(y, y_ref) < 5e-6
+    assert relerr(xd.grad, x.grad) < 2e-5
+
+
+def test_input_stage():
+    from mdm_hip import ops
+
+    u = torch.randint(0, 256, (3, 20, 28, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    ref = torch.permute((u.type(torch.float) - 127.0) / 128.0, (0, 3, 1, 2))   # clis/train_parallel.py:194-195
+    out = ops.input_stage(u.to(DEV))
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_gpu_get_loss_equals_cpu_formulation():
+    """Diffusion.get_loss / NestedDiffusion.get_loss with a stub denoiser: the fused GPU path (noise_images, avgpool,
+    diffusion_loss) == the torch formulation on CPU, incl. the gradient that reaches the denoiser output"""
+    import stub_models as SM
+    from mdm_hip import diffusion as D
+    from mdm_hip import samplers as S
+
+    g = torch.Generator().manual_seed(7)
+    for nested in (False, True):
+        sc = S.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
+                             loss_target_type="DDPM", schedule_shifted=nested, rescale_signal=1 if nested else None)
+        side = 32 if nested else 16
+        smp = {"images": torch.rand(3, 3, side, side, generator=g) * 2 - 1, "lm_outputs": torch.randn(3, 5, 8, generator=g),
+               "lm_mask": torch.ones(3, 5)}
+        res = []
+        for dev in ("cpu", DEV):
+            if nested:
+                pipe = D.NestedDiffusion(SM.StubNestedUNet(), D.NestedDiffusionConfig(
+                    sampler_config=sc, use_vdm_loss_weights=False, use_double_loss=True, no_use_residual=True, multi_res_weights="4:1"))
+            else:
+                pipe = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=sc, use_vdm_loss_weights=False))
+            pipe = pipe.to(torch.device(dev))
+            gg = torch.Generator().manual_seed(11)
+            draws = [torch.randn(3, 3, side, side, generator=gg), torch.randn(3, 3, side // 4, side // 4, generator=gg)]
+            it = iter(draws)
+            s = {k: v.to(dev) for k, v in smp.items()}
+            out = pipe.get_loss(s, time=torch.tensor([3, 500, 990]).to(dev), noise_fn=lambda like: next(it).to(like.device))
+            out[0].sum().backward()
+            w = pipe.get_model().vision_model.w
+            res.append((out[0].detach().cpu(), out[2].detach().cpu(), out[4].detach().cpu(), w.grad.detach().cpu().clone()))
+        for a, b in zip(res[1], res[0]):
+            assert relerr(a, b) < 1e-5

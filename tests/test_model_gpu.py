@@ -3,8 +3,9 @@
   * the golden vectors produced by the real reference (tests/golden/*.pt)
 
 Tolerances (rel-L2): fp32 mode outputs 1e-4, gradients 1e-3 (SURVEY.md section 8d parity gates;
-oracle fp32-vs-fp64 noise is ~1e-6).  bf16 mode: outputs 3e-2, gradients 6e-2 -- the reference's
-own bf16-autocast forward error against fp64 is 1.3e-2 on UNet-64.
+oracle fp32-vs-fp64 noise is ~1e-6).  bf16 mode: outputs 1.3e-2 -- the reference's own bf16-autocast
+forward error against fp64 on UNet-64 (SURVEY.md section 8c) -- and 3e-2 on the aggregate gradient;
+the measured values are printed (pytest -s / the captured-output section of a failure).
 """
 import os
 
@@ -49,16 +50,19 @@ def test_fp32_matches_oracle_and_golden(name):
         assert abs(float(grads[k].double().norm()) - n) <= 1e-3 * max(n, floor), k
 
 
-@pytest.mark.parametrize("name", ["mini_unet", "mini_nested"])
+@pytest.mark.parametrize("name", ["mini_unet", "mini_nested", "mini_nested2"])
 def test_bf16_close_to_oracle(name):
+    """bf16 mode vs the fp32 oracle: measured errors are printed; gates = the reference's own bf16-autocast forward
+    error (1.3e-2) and 3e-2 on the aggregate parameter gradient"""
     outs, grads = hip_run(name, torch.bfloat16)
     o_ref, g_ref = PC.oracle_run(name)
-    for a, b in zip(outs, o_ref):
-        assert O.rel_l2(a, b) < 3e-2
+    errs = [O.rel_l2(a, b) for a, b in zip(outs, o_ref)]
     # aggregate gradient error over all parameters (individual tiny tensors are noisier)
     num = sum(float((grads[k].double().cpu() - g_ref[k].double()).pow(2).sum()) for k in g_ref)
     den = sum(float(g_ref[k].double().pow(2).sum()) for k in g_ref)
-    assert (num / den) ** 0.5 < 6e-2
+    agg = (num / den) ** 0.5
+    print("[bf16 %s] forward rel-L2 %s, aggregate gradient rel-L2 %.3e" % (name, ["%.3e" % e for e in errs], agg))
+    assert max(errs) < 1.3e-2 and agg < 3e-2
 
 
 def test_forward_is_deterministic():
@@ -192,53 +196,136 @@ def test_weights_are_repacked_after_an_optimizer_step():
     assert O.rel_l2(y1.cpu(), y_ref) < 1e-4             # ... and it is exactly the updated parameters
 
 
-@pytest.mark.parametrize("which", ["unet64", "nested256"])
-def test_full_size_architectures_match_oracle(which):
-    """BASELINE.json configs[1]/[2] architectures at FULL size (461 M / 477 M parameters), batch 1, fp32 mode:
-    forward output (and, for UNet-64, every parameter gradient) of the HIP path vs the CPU oracle on the same
-    seeded weights.  Also a size-independent property: the bf16 run of the same input stays within the bf16 gate."""
-    import mdm_hip
-    from mdm_hip import configs
+def _full_gold(name):
+    return torch.load(os.path.join(GOLD, "full_size.pt"), weights_only=False)[name]
 
-    torch.manual_seed(0)
-    if which == "unet64":
-        cfg_fn, cls, side = (lambda: configs.unet64_config(2048)), mdm_hip.UNet, 64
-    else:
-        cfg_fn, cls, side = (lambda: configs.nested256_config(2048)), mdm_hip.NestedUNet, 256
-    model = cls(3, 3, cfg_fn())
-    sd = O.randomize_zero_params(model.state_dict(), seed=99)
-    model.load_state_dict(sd)
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(1, 3, side, side, generator=g)
-    xs = [x, torch.randn(1, 3, 64, 64, generator=g)] if which == "nested256" else x
-    cond, mask, times = torch.randn(1, 32, 2048, generator=g), torch.ones(1, 32), torch.tensor([417])
-    gys = [torch.randn(t.shape, generator=g) for t in PC.as_list(xs)]
-    with_grad = which == "unet64"
 
-    leaf = {k: v.clone().requires_grad_(with_grad) for k, v in sd.items()}
-    o_ref = PC.as_list(O.model_forward(leaf, cfg_fn(), xs, times, cond, mask))
-    if with_grad:
-        PC.loss_of(o_ref, gys).backward()
-    o_ref = [o.detach() for o in o_ref]
+def _agg_grad_err(grads, gold):
+    """aggregate ||g - g_ref|| / ||g_ref|| over all parameters, estimated from the golden file's seeded random
+    projections: E[<g - g_ref, probe>^2] = ||g - g_ref||^2 for a unit-variance probe, summed over ~700 tensors"""
+    num = sum((float((grads[k].detach().double().cpu() * PC.probe_for(k, grads[k].shape)).sum()) - pr) ** 2
+              for k, pr in gold["grad_probe"].items())
+    den = sum(n * n for n in gold["grad_norm"].values())
+    return (num / den) ** 0.5
 
+
+@pytest.mark.parametrize("which", list(PC.FULL))
+def test_full_size_architectures_match_reference(which):
+    """The SHIPPED architectures at full size (BASELINE.json configs[0..4]: 461 M / 477 M / 481 M parameters), HIP
+    path vs what the REAL reference produced on the same seeded weights / inputs (tests/golden/full_size.pt):
+      fp32 mode: every output (1e-4) and -- unet64 (B=2), nested256 -- every parameter gradient through its norm and a
+                 seeded random projection (2e-3 of max(norm, floor));
+      bf16 mode: forward error and the aggregate gradient error are PRINTED and gated at the reference's own
+                 bf16-autocast-vs-fp64 forward error, 1.3e-2; gradients at 3e-2.
+    nested1024 exercises the x / std input normalisation kernel of its 256 level (models/unet.py:871-872)."""
+    gold = _full_gold(which)
+    model, _ = PC.full_module(which)
+    inp = PC.full_inputs(which)
     model = model.cuda()
-    xs_d = [t.cuda() for t in xs] if isinstance(xs, list) else xs.cuda()
+    xs = [t.cuda() for t in inp["x"]] if isinstance(inp["x"], list) else inp["x"].cuda()
+    args = (xs, inp["times"].cuda(), inp["cond"].cuda(), inp["mask"].cuda())
+    with_grad = "grad_norm" in gold
+    with torch.set_grad_enabled(with_grad):
+        out = PC.as_list(model(*args))
+    for i, (o, gd) in enumerate(zip(out, gold["outputs"])):
+        PC.check_summary(o.float(), gd, "%s.out%d" % (which, i), 1e-4)
     if with_grad:
-        out = PC.as_list(model(xs_d, times.cuda(), cond.cuda(), mask.cuda()))
-        PC.loss_of(out, gys).backward()
-    else:
-        with torch.no_grad():
-            out = PC.as_list(model(xs_d, times.cuda(), cond.cuda(), mask.cuda()))
-    for a, b in zip(out, o_ref):
-        assert O.rel_l2(a.float().cpu(), b) < 1e-4
+        PC.loss_of(out, inp["gys"]).backward()
+        grads = {k: p.grad for k, p in model.named_parameters()}
+        norms = sorted(gold["grad_norm"].values())
+        floor = 1e-2 * norms[len(norms) // 2]
+        for k, n in gold["grad_norm"].items():
+            gk = grads[k].double().cpu()
+            assert abs(float(gk.norm()) - n) <= 2e-3 * max(n, floor), k
+            probe = float((gk * PC.probe_for(k, gk.shape)).sum())
+            assert abs(probe - gold["grad_probe"][k]) <= 8e-3 * max(n, floor), k
+        agg32 = _agg_grad_err(grads, gold)
+        model.zero_grad(set_to_none=True)
+    # bf16 mode on the same input
+    with torch.set_grad_enabled(with_grad), torch.autocast("cuda", dtype=torch.bfloat16):
+        out16 = PC.as_list(model(*args))
+    errs = []
+    for i, (o, gd) in enumerate(zip(out16, gold["outputs"])):
+        st = max(1, o.shape[-1] // 64)
+        errs.append(O.rel_l2(o.float()[..., ::st, ::st], gd["sub"]))
+    msg = "[bf16 %s] forward rel-L2 vs reference fp32: %s" % (which, ", ".join("%.3e" % e for e in errs))
     if with_grad:
-        errs, _ = PC.grad_errors({k: p.grad for k, p in model.named_parameters()}, {k: v.grad for k, v in leaf.items()})
-        worst = max((e, k) for k, e in errs.items())
-        assert worst[0] < 2e-3, worst
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        out16 = PC.as_list(model(xs_d, times.cuda(), cond.cuda(), mask.cuda()))
-    for a, b in zip(out16, o_ref):
-        assert O.rel_l2(a.float().cpu(), b) < 3e-2
+        PC.loss_of(out16, inp["gys"]).backward()
+        agg16 = _agg_grad_err({k: p.grad for k, p in model.named_parameters()}, gold)
+        msg += "; aggregate parameter-gradient error fp32 %.2e, bf16 %.3e" % (agg32, agg16)
+    print(msg)
+    assert max(errs) <= 1.3e-2, msg
+    if with_grad:
+        assert agg32 < 5e-4 and agg16 < 3e-2, msg
+
+
+def test_config0_pipeline_at_full_size():
+    """BASELINE.json configs[0] at its REAL size: cc12m_64x64 U-Net (461 M parameters), batch 2, 4 diffusion steps
+    (DDIM eta=0), random text embeddings; Diffusion.sample() and get_loss() through the HIP denoiser and the fused
+    sampler / loss kernels vs the images / losses the real reference pipeline produced on CPU.
+    Gate: 1e-3 rel-L2 (north_star: "sampled images within 1e-3 rel-L2 of reference")."""
+    gold = _full_gold("unet64")
+    model, _ = PC.full_module("unet64")
+    pipe = _pipeline("mini_unet", model).to(torch.device("cuda:0"))
+    inp = PC.full_inputs("unet64")
+    smp = {"lm_outputs": inp["cond"].cuda(), "lm_mask": inp["mask"].cuda()}
+    torch.manual_seed(23)
+    with torch.no_grad():
+        img = pipe.sample(2, smp, 64, torch.device("cuda:0"), resample_steps=True, num_inference_steps=4, ddim_eta=0)
+    e_img = O.rel_l2(img.cpu(), gold["sample"])
+    g = torch.Generator().manual_seed(29)
+    smp["images"] = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).cuda()
+    torch.manual_seed(31)
+    time = torch.randint(0, 1000, (2,))
+    eps = torch.randn(2, 3, 64, 64)
+    pipe.train()
+    loss = pipe.get_loss(smp, time=time.cuda(), noise_fn=lambda like: eps.to(like.device))[0]
+    e_loss = O.rel_l2(loss.float().cpu(), gold["loss"])
+    print("[configs[0], full size] 4-step sample rel-L2 %.3e, train loss rel-L2 %.3e" % (e_img, e_loss))
+    assert e_img < 1e-3 and e_loss < 1e-3
+
+
+def test_residual_gradient_with_two_consumers_under_async_wgrad():
+    """ConvFn.backward hands `dy` on as the gradient of its residual input while the side stream still reads it for
+    the weight gradient.  When that tensor has a second consumer the engine ACCUMULATES into the first gradient;
+    it must not do so in place under the side stream's reads."""
+    from mdm_hip import ops
+
+    class Sink:
+        def __init__(self, params):
+            self.slots = {p.data_ptr(): torch.zeros_like(p) for p in params}
+
+        def slot(self, p):
+            return self.slots.get(p.data_ptr())
+
+        def ready(self, p):
+            pass
+
+    g = torch.Generator().manual_seed(1)
+    N, H, C = 8, 32, 256
+    x0 = torch.randn(N, H, H, C, generator=g).cuda().to(torch.bfloat16)
+    h0 = torch.randn(N, H, H, C, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(C, C, 3, 3, generator=g) / 48).cuda().requires_grad_()
+    b = torch.zeros(C).cuda().requires_grad_()
+    res = []
+    for async_on in (False, True):
+        sink = Sink([w, b])
+        ops.set_grad_sink(sink)
+        ops.enable_async_wgrad(async_on)
+        x = x0.clone().requires_grad_()
+        h = h0.clone().requires_grad_()
+        y = ops.conv(h, w, b, residual=x)          # dres = dy lands first in x's input buffer ...
+        z = ops.silu(x)                            # ... and the second consumer's gradient is added to it
+        for _ in range(6):                         # keep the side stream busy while the main stream moves on
+            y = ops.conv(y, w, b, residual=x)
+        (y.float().square().sum() * 1e-3 + z.float().sum()).backward()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        res.append((x.grad.clone(), sink.slots[w.data_ptr()].clone()))
+    ops.set_grad_sink(None)
+    ops.enable_async_wgrad(False)
+    assert torch.equal(res[0][0], res[1][0])
+    assert O.rel_l2(res[1][1], res[0][1]) < 1e-6   # same kernels, same summation order: the side stream only moves them
 
 
 @pytest.mark.parametrize("name", ["mini_unet", "mini_nested"])

@@ -197,6 +197,12 @@ def test_ffn(dtype):
     (3, 256, 512, 32, False, False),   # no activation
     (2, 400, 1536, 32, True, True),    # 48 / group (one group per block), 4 passes
     (2, 256, 256, 32, False, True),    # 8 / group, 8 groups per block
+    # large images: partial -> apply with the per-block finalize of a channel slice
+    (2, 4096, 256, 32, True, True),    # the 64x64 level: 64-channel slices, 8 groups each
+    (2, 4096, 768, 32, False, True),   # skip-concat width: 24 / group -> 96-channel slices
+    (3, 1024, 1280, 32, True, True),   # 40 / group -> 80-channel slices (backward only: forward is register-resident)
+    (2, 2304, 32, 32, False, True),    # nested outer level: 1 channel / group, the slice is the whole row
+    (5, 900, 128, 32, False, False),   # 4 / group; pixel count not a multiple of anything
 ])
 def test_group_norm(dtype, N, HW, C, G, film, silu):
     from mdm_hip import ops

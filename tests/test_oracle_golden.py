@@ -43,8 +43,35 @@ def test_oracle_fp64_noise_floor(name):
         assert O.rel_l2(a, b) < 1e-5
 
 
+@pytest.mark.parametrize("name", list(PC.FULL))
+def test_oracle_matches_full_size_golden(name):
+    """the SHIPPED architectures at full size (461 M / 477 M / 481 M parameters): oracle == what the real reference
+    produced for tests/golden/full_size.pt (outputs through their summaries; every parameter gradient through its norm
+    and a seeded random projection).  nested1024 covers the x / std input normalisation of its 256 level."""
+    gold = torch.load(os.path.join(GOLD, "full_size.pt"), weights_only=False)[name]
+    _, sd = PC.full_module(name)
+    for k, s in gold["param_sum"].items():
+        assert abs(float(sd[k].double().sum()) - s) <= 1e-9 * max(1.0, abs(s)), k
+    inp = PC.full_inputs(name)
+    with_grad = "grad_norm" in gold
+    leaf = {k: v.clone().requires_grad_(with_grad) for k, v in sd.items()}
+    with torch.set_grad_enabled(with_grad):
+        outs = PC.as_list(O.model_forward(leaf, PC.full_cfg(name), inp["x"], inp["times"], inp["cond"], inp["mask"]))
+    for i, (o, g) in enumerate(zip(outs, gold["outputs"])):
+        PC.check_summary(o, g, "%s.out%d" % (name, i), 2e-6)
+    if with_grad:
+        PC.loss_of(outs, inp["gys"]).backward()
+        norms = sorted(gold["grad_norm"].values())
+        floor = 1e-2 * norms[len(norms) // 2]
+        for k, n in gold["grad_norm"].items():
+            g = leaf[k].grad.double()
+            assert abs(float(g.norm()) - n) <= 1e-4 * max(n, floor), k
+            probe = float((g * PC.probe_for(k, g.shape)).sum())
+            assert abs(probe - gold["grad_probe"][k]) <= 4e-4 * max(n, floor), k
+
+
 @pytest.mark.reference
-@pytest.mark.parametrize("name", ["mini_unet", "mini_nested"])
+@pytest.mark.parametrize("name", ["mini_unet", "mini_nested", "mini_nested2"])
 def test_oracle_matches_live_reference(name):
     import dataclasses
 
@@ -58,7 +85,9 @@ def test_oracle_matches_live_reference(name):
         inner = d.pop("inner_config", None)
         if inner is None:
             return R.unet.UNetConfig(resnet_config=rc, **d)
-        return R.nested_unet.NestedUNetConfig(resnet_config=rc, inner_config=conv(inner), **d)
+        icfg = conv(inner)
+        cls = R.nested_unet.Nested2UNetConfig if hasattr(icfg, "inner_config") else R.nested_unet.NestedUNetConfig
+        return cls(resnet_config=rc, inner_config=icfg, **d)
 
     _, cfg, sd = PC.build_module(name)
     rcfg = conv(cfg)
