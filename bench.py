@@ -6,22 +6,26 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the hot path over one synthetic batch: Diffusion.get_loss (noising +
-U-Net forward) -> backward -> gradient all-reduce (N > 1) -> clip -> AdamW -> EMA, i.e. the
+U-Net forward + loss) -> backward -> gradient all-reduce (N > 1) -> clip -> AdamW -> EMA, i.e. the
 reference's ``trainer.train_batch`` (trainer.py:13-96).  Inputs are resident in HBM before the
-timed region.  Rank 0 prints ONE JSON line (contract in the task statement) with two extra
-objects: ``roofline`` (dominant kernel, measured live with HIP events on the launch stream)
-and ``cpu_baseline`` (the CPU oracle timed on this box's host cores, rank 0 / N=1 only).
+timed region.  Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline      the GEMM-class kernel with the largest total time of a step, measured live with HIP events on the
+                launch stream; ``gemm_weighted`` = FLOP-weighted figure over every GEMM-class launch;
+                ``hbm_kernels`` = the streaming kernels as algorithmic GB/s against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (a port of the reference path) on this box's host cores, rank 0 / N = 1 only
+  sampling      ms per denoise step (DDIM, whole iteration: model + fused update)
+  nested256     BASELINE.json configs[2] (cc12m_256x256 NestedUNet, bf16, batch 16): steps/s of the same train step
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (os.path.join(ROOT, "ml-mdm_amd"), os.path.join(ROOT, "oracle")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if os.path.join(ROOT, "ml-mdm_amd") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "ml-mdm_amd"))
 sys.dont_write_bytecode = True
 
 import torch  # noqa: E402
@@ -31,12 +35,14 @@ import torch.distributed as dist  # noqa: E402
 FWD_GFLOP_PER_SAMPLE = {"unet64": 363.9, "nested256": 589.1, "mini": 0.0}
 PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0       # HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s measured for a float4 copy)
+PMC_FILES = ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
 
 
 def build(workload, device, seed=0):
-    import unet_oracle as O
     import mdm_hip
     from mdm_hip import configs, diffusion, samplers
+    from mdm_hip.testing import randomize_zero_params
 
     sc = samplers.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
                                 loss_target_type="DDPM", threshold_function="CLIP")
@@ -53,7 +59,7 @@ def build(workload, device, seed=0):
         dcfg = diffusion.NestedDiffusionConfig(sampler_config=sc, use_vdm_loss_weights=False, use_double_loss=True, no_use_residual=True)
         pipe_cls, side = diffusion.NestedDiffusion, 256
     # the reference zero-initialises ~40% of the tensors; randomise them (seeded) so no work is degenerate
-    net.load_state_dict(O.randomize_zero_params(net.state_dict(), seed=4321))
+    net.load_state_dict(randomize_zero_params(net.state_dict(), seed=4321))
     pipe = pipe_cls(net, dcfg).to(device)
     return pipe, side
 
@@ -68,22 +74,24 @@ def synthetic_batch(batch, side, device, seed):
 
 
 def pmc_traffic(kernel_label):
-    """HBM bytes per launch of the named kernel from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json, built
-    by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, with the gfx950
-    FETCH_SIZE x2 correction).  ``kernel_label`` is the kernel name as rocprofv3 prints it (without arguments);
-    None when there is no measurement for it."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
-    table = json.load(open(path))["kernels"]
-    for k, v in table.items():
-        if kernel_label in k:
-            return v["hbm_bytes_per_launch"]
-    return None
+    """(HBM bytes per launch, source file) of the named kernel from the committed PMC passes (profiles/rNN_pmc_hbm_traffic.json,
+    built by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, with the
+    gfx950 FETCH_SIZE x2 correction).  PMC collection needs rocprofv3, so this is a lookup, not a live measurement."""
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        for k, v in json.load(open(path))["kernels"].items():
+            if kernel_label in k:
+                return v["hbm_bytes_per_launch"], "profiles/" + name
+    return None, None
 
 
 def cpu_baseline(workload, batch_ref):
-    """the oracle (CPU restatement of the reference path) fwd+bwd on the host cores; bounded sample"""
+    """The CPU oracle (oracle/unet_oracle.py, a port of the reference path pinned to it by tests/golden) fwd+bwd on the
+    host cores: per batch size 1 warm-up + timed iterations, median.  The real reference classes timed in the build
+    container are in profiles/r02_cpu_reference_real.json (the reference tree does not exist on the GPU box)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import unet_oracle as O
     import mdm_hip
     from mdm_hip import configs
@@ -92,31 +100,52 @@ def cpu_baseline(workload, batch_ref):
     # vs ~10 s at 8 for the same work), so the baseline uses at most 32 host threads and reports that count
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    b = 8 if workload == "unet64" else 2   # ~10 s of host work at 32 threads
     side = 64 if workload == "unet64" else 256
     torch.manual_seed(0)
-    cfg = configs.unet64_config(2048) if workload == "unet64" else configs.nested256_config(2048)
+    cfg_fn = (lambda: configs.unet64_config(2048)) if workload == "unet64" else (lambda: configs.nested256_config(2048))
     cls = mdm_hip.UNet if workload == "unet64" else mdm_hip.NestedUNet
-    sd = O.randomize_zero_params(cls(3, 3, cfg).state_dict(), seed=4321)
+    sd = O.randomize_zero_params(cls(3, 3, cfg_fn()).state_dict(), seed=4321)
     leaf = {k: v.requires_grad_(True) for k, v in sd.items()}
-    cfg = configs.unet64_config(2048) if workload == "unet64" else configs.nested256_config(2048)
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(b, 3, side, side, generator=g)
-    if workload != "unet64":
-        x = [x, torch.randn(b, 3, 64, 64, generator=g)]
-    cond, mask = torch.randn(b, 32, 2048, generator=g), torch.ones(b, 32)
-    t0 = time.perf_counter()
-    out = O.model_forward(leaf, cfg, x, torch.randint(0, 1000, (b,), generator=g), cond, mask)
-    loss = sum(o.square().mean() for o in (out if isinstance(out, list) else [out]))
-    loss.backward()
-    dt = time.perf_counter() - t0
+    per_batch = {}
+    for b, timed in ((2, 3), (8, 2)) if workload == "unet64" else ((2, 2),):
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(b, 3, side, side, generator=g)
+        if workload != "unet64":
+            x = [x, torch.randn(b, 3, 64, 64, generator=g)]
+        cond, mask, t = torch.randn(b, 32, 2048, generator=g), torch.ones(b, 32), torch.randint(0, 1000, (b,), generator=g)
+        times = []
+        for it in range(1 + timed):
+            for v in leaf.values():
+                v.grad = None
+            t0 = time.perf_counter()
+            out = O.model_forward(leaf, cfg_fn(), x, t, cond, mask)
+            sum(o.square().mean() for o in (out if isinstance(out, list) else [out])).backward()
+            if it > 0:
+                times.append(time.perf_counter() - t0)
+        per_batch[b] = statistics.median(times)
+    b_big = max(per_batch)
     return {
-        "value": round((b / batch_ref) / dt, 6),
+        "value": round((b_big / batch_ref) / per_batch[b_big], 6),
         "unit": "denoise-steps/s (batch %d equivalent)" % batch_ref,
         "cores": cores,
         "kind": "port",
-        "sample": "1 un-warmed fwd+bwd of the fp32 CPU oracle at batch %d (%.1f s), scaled by %d/%d" % (b, dt, b, batch_ref),
+        "sample": "fp32 CPU oracle fwd+bwd, 1 warm-up + median of the timed iterations: " + ", ".join(
+            "batch %d %.2f s (%.3f samples/s)" % (b, s, b / s) for b, s in sorted(per_batch.items())) +
+            "; value = batch-%d rate scaled by %d/%d" % (b_big, b_big, batch_ref),
+        "samples_per_s": {str(b): round(b / s, 4) for b, s in per_batch.items()},
+        "real_reference": "profiles/r02_cpu_reference_real.json (ml_mdm classes, build container)",
     }
+
+
+def timed_steps(step, sample, warmup, steps, sync):
+    for _ in range(warmup):
+        step(sample)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(sample)
+    sync()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -127,9 +156,12 @@ def main():
     ap.add_argument("--workload", default="unet64", choices=["unet64", "nested256", "mini"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 / 16)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--bucket-mb", type=float, default=256.0, help="gradient all-reduce bucket size (N > 1)")
+    ap.add_argument("--wire-bf16", action="store_true", help="all-reduce gradients in bf16 (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
+    ap.add_argument("--no-nested", action="store_true", help="skip the nested256 (configs[2]) sub-measurement")
     ap.add_argument("--sample-batch", type=int, default=None)
     args = ap.parse_args()
 
@@ -146,37 +178,31 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     batch = args.batch or {"unet64": 64, "nested256": 16, "mini": 4}[args.workload]
-
-    pipe, side = build(args.workload, device)
-    step = TrainStep(pipe, bf16=args.dtype == "bf16")
-    sample = synthetic_batch(batch, side, device, seed=1234 + rank)
+    bf16 = args.dtype == "bf16"
+    wire = torch.bfloat16 if args.wire_bf16 else None
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(sample)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(sample)
-    sync()
-    dt = time.perf_counter() - t0
+    pipe, side = build(args.workload, device)
+    step = TrainStep(pipe, bf16=bf16, bucket_mb=args.bucket_mb, wire_dtype=wire)
+    sample = synthetic_batch(batch, side, device, seed=1234 + rank)
+    dt = timed_steps(step, sample, args.warmup, args.steps, sync)
     if world > 1:
         tt = torch.tensor([dt], device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # secondary metric: sampling throughput (replicas only: every rank samples its own prompts, no collective)
+    # secondary metric: sampling latency (replicas only: every rank samples its own prompts, no collective)
     samp = None
     if not args.no_sampling:
         n_it = 6
         pipe.eval()
         sb = args.sample_batch or batch
         ssample = synthetic_batch(sb, side, device, seed=4321 + rank)
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
             pipe.sample(sb, ssample, side, device, resample_steps=True, num_inference_steps=2, ddim_eta=0)  # warm-up
             sync()
             ts = time.perf_counter()
@@ -189,27 +215,49 @@ def main():
                 round(world * sb / (demo_steps * ms_it / 1e3), 3), "sampler": "DDIM eta=0, CFG off", "timed_steps": n_it}
     roof = None
     if not args.no_roofline:
-        # one extra, untimed step with HIP events around every GEMM-class launch (on the launch stream).  Every rank
-        # runs the step (it contains the gradient all-reduce); only rank 0 records and reports.
+        # one extra, untimed step with HIP events around every GEMM-class / streaming launch (on the launch stream).
+        # Every rank runs the step (it contains the gradient all-reduce); only rank 0 records and reports.
         pipe.train()
         if rank == 0:
             ops.profile_begin()
         step(sample)
         torch.cuda.synchronize()
         if rank == 0:
-            roof = ops.profile_end(PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS)
-            if roof is not None and args.workload == "unet64" and args.dtype == "bf16" and batch == 64:
-                roof["traffic"] = pmc_traffic(roof["kernel"])   # HBM bytes per launch (PMC), null if not collected
+            roof = ops.profile_end(PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS, PEAK_HBM_GBS)
+            if roof is not None and args.workload == "unet64" and bf16 and batch == 64:
+                roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"])   # HBM bytes per launch (PMC), null if not collected
     if world > 1:
         dist.barrier()
+
+    # BASELINE.json configs[2]: the nested 64+256 train step at batch 16, same protocol, fewer steps
+    nested = None
+    if args.workload == "unet64" and not args.no_nested and bf16:
+        del step
+        ops.set_grad_sink(None)
+        pipe = sample = None
+        torch.cuda.empty_cache()
+        npipe, nside = build("nested256", device)
+        nstep = TrainStep(npipe, bf16=True, bucket_mb=args.bucket_mb, wire_dtype=wire)
+        nsample = synthetic_batch(16, nside, device, seed=99 + rank)
+        nsteps = max(3, min(args.steps, 10))
+        ndt = timed_steps(nstep, nsample, 2, nsteps, sync)
+        if world > 1:
+            tt = torch.tensor([ndt], device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ndt = float(tt.item())
+        nflop = 3 * FWD_GFLOP_PER_SAMPLE["nested256"] * 16 / 1e3
+        nested = {"workload": "cc12m_256x256 NestedUNet (64+256) train step, bf16, per-GPU batch 16", "steps": nsteps,
+                  "ms_per_step": round(ndt / nsteps * 1e3, 3), "steps_per_s_whole_job": round(world * nsteps / ndt, 4),
+                  "step_algorithmic_tflop": round(nflop, 2),
+                  "step_mfma_roofline_frac": round(nflop / (ndt / nsteps) / PEAK_BF16_TFLOPS, 4)}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         steps_per_s = world * args.steps / dt
         alg_tflop_step = 3 * FWD_GFLOP_PER_SAMPLE[args.workload] * batch / 1e3
         out = {
-            "metric": "denoise-steps/sec (train fwd+bwd+optimizer, %s, batch %d per GPU)" % (
-                "cc12m_64x64 U-Net" if args.workload == "unet64" else "cc12m_256x256 NestedUNet", batch),
+            "metric": "denoise-steps/sec, whole job = N x optimizer steps/s at per-GPU batch %d (train fwd+bwd+optimizer, %s)" % (
+                batch, "cc12m_64x64 U-Net" if args.workload == "unet64" else "cc12m_256x256 NestedUNet"),
             "value": round(steps_per_s, 4),
             "unit": "steps/s",
             "n_gpus": world,
@@ -225,12 +273,17 @@ def main():
                 "workload": "%s train step, per-GPU batch %d, global batch %d" % (args.workload, batch, batch * world),
                 "global_batch": batch * world,
                 "parallelism": "dp%d" % world,
+                "optimizer_steps_per_s": round(args.steps / dt, 4),
                 "samples_per_s": round(steps_per_s * batch, 2),
                 "step_algorithmic_tflop": round(alg_tflop_step, 2),
-                "step_mfma_roofline_frac": round(alg_tflop_step / (ms / 1e3) / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4),
+                "step_mfma_roofline_frac": round(alg_tflop_step / (ms / 1e3) / (PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS), 4),
+                "comm": {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
+                         "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+                         "bucket_mb": args.bucket_mb, "wire_dtype": "bf16" if args.wire_bf16 else "fp32"},
             },
             "roofline": roof,
             "sampling": samp,
+            "nested256": nested,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, batch)

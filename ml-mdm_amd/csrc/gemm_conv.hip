@@ -1596,6 +1596,14 @@ static int conv_tile_code(int M, int Cout, int dtype) {
 
 extern "C" int mdm_conv_fwd_tile(int M, int Cout, int dtype) { return conv_tile_code(M, Cout, dtype); }
 
+// EXPERIMENT (round 2, to be settled by measurement): short-K 1x1 GEMMs on a 128x192 tile with TWO 4-wave blocks per
+// CU (80 KB LDS each), so that one block's epilogue (LDS staging + stores) overlaps the other's k-loop.
+static int exp_tile() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MDM_HIP_TILE_EXP"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 template <typename T, int MODE>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE>(a, st);
@@ -1604,6 +1612,10 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if constexpr (MODE != MODE_3x3_T2) {
       if (conv_bl_ok<T, MODE>(a)) {
+        if constexpr (MODE == MODE_1x1) {
+          const int ex = exp_tile();
+          if (ex && a.Cout % 192 == 0 && a.K <= ex && a.M >= 8192) return launch_conv_bl<128, 192, 2, 2, MODE>(a, st);
+        }
         if (code == 256256) return launch_conv_bl<256, 256, 2, 4, MODE>(a, st);
         if (code == 256192) return launch_conv_bl<256, 192, 2, 4, MODE>(a, st);
         return launch_conv_bl<128, 128, 2, 2, MODE>(a, st);
@@ -1661,7 +1673,9 @@ static void wgrad_choose(int M, int Cout, int K, int dtype, int* te_out, int* sp
   for (int te = 128; te <= 256; te += 128) {
     if (te == 256 && !(dtype == DT_BF16 && Cout >= 192 && K >= 192)) continue;
     const int tiles = ((Cout + te - 1) / te) * ((K + te - 1) / te);
-    const int slots = te == 256 ? 256 : 512;
+    static int slot_div = 0;   // EXPERIMENT: several weight-gradient streams share the chip (MDM_HIP_WGRAD_STREAMS)
+    if (!slot_div) { const char* e = getenv("MDM_HIP_WGRAD_STREAMS"); slot_div = e && atoi(e) > 0 ? atoi(e) : 1; }
+    const int slots = (te == 256 ? 256 : 512) / slot_div;
     const double t_tile = (te == 256 ? 1.7 : 1.06) * (dtype == DT_F32 ? 8.0 : 1.0), t_fix = te == 256 ? 12.0 : 5.0;
     const int smax = mt_total < 64 ? mt_total : 64;
     for (int sp = 1; sp <= smax; ++sp) {

@@ -101,10 +101,33 @@ def enable_async_wgrad(flag: bool):
     _async_wgrad = bool(flag)
 
 
+_side_streams = []
+_side_rr = 0
+
+
+def _make_side_stream():
+    """EXPERIMENT switches (round 2, settled by measurement then removed): MDM_HIP_SIDE_CUMASK=<hex word> pins the
+    weight-gradient stream to a subset of the CUs (hipExtStreamCreateWithCUMask, the word repeated over all CUs)."""
+    mask = os.environ.get("MDM_HIP_SIDE_CUMASK")
+    if not mask:
+        return torch.cuda.Stream()
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (ctypes.c_uint32 * 8)(*([int(mask, 16)] * 8))
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+    if rc != 0:
+        raise _lib.MdmHipError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    return torch.cuda.ExternalStream(st.value)
+
+
 def side_stream():
-    global _side_stream
-    if _side_stream is None:
-        _side_stream = torch.cuda.Stream()
+    """the weight-gradient stream (round-robin over MDM_HIP_WGRAD_STREAMS of them: experiment)"""
+    global _side_stream, _side_rr
+    if not _side_streams:
+        n = max(1, int(os.environ.get("MDM_HIP_WGRAD_STREAMS", "1")))
+        _side_streams.extend(_make_side_stream() for _ in range(n))
+    _side_stream = _side_streams[_side_rr % len(_side_streams)]
+    _side_rr += 1
     return _side_stream
 
 
@@ -118,8 +141,8 @@ _side_keep = []
 
 def join_side_stream():
     """make the current stream wait for everything queued on the weight-gradient stream"""
-    if _side_stream is not None:
-        torch.cuda.current_stream().wait_stream(_side_stream)
+    for st in _side_streams:
+        torch.cuda.current_stream().wait_stream(st)
     _side_keep.clear()   # every later main-stream write is ordered behind the side stream's reads now
 
 
@@ -138,8 +161,7 @@ def _off_critical_path(tensors, fn):
         t.record_stream(side)
     _side_keep.append((done, live))
     if len(_side_keep) >= 64:
-        while _side_keep and _side_keep[0][0].query():
-            _side_keep.pop(0)
+        _side_keep[:] = [e for e in _side_keep if not e[0].query()]
 
 
 def _cache_slot(weight):
@@ -197,57 +219,66 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
 
 
 # --------------------------------------------------------------------------------------
-# optional per-launch timing of the GEMM-class kernels (bench.py roofline leg)
+# optional per-launch timing (bench.py roofline leg): HIP events on the launch stream around every GEMM-class launch
+# (with its algorithmic FLOPs) and every large streaming launch (with its algorithmic HBM bytes)
 # --------------------------------------------------------------------------------------
 _prof = None
-_prof_shapes = os.environ.get("MDM_HIP_PROF_SHAPES", "0") == "1"   # development: key the table by GEMM shape as well
+_prof_shapes = False
 
 
-def profile_begin():
-    """Start recording HIP events (on the launch stream = torch's current stream) around every
-    conv / wgrad launch, together with the algorithmic FLOPs of the launch."""
-    global _prof
-    _prof = []
+def profile_begin(shapes: bool = False):
+    """Start recording.  ``shapes``: key the GEMM table by problem shape as well (tools/)."""
+    global _prof, _prof_shapes
+    _prof, _prof_shapes = [], shapes
 
 
-def _prof_wrap(name, flops, fn):
+def _prof_wrap(name, work, fn, kind="mfma"):
     if _prof is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    real = _lib.lib().mdm_last_gemm_kernel()   # the kernel that actually ran (name as rocprofv3 prints it)
-    if real:
-        name = real.decode() + (name[name.index(" M="):] if " M=" in name else "")
-    _prof.append((name, flops, e0, e1))
+    if kind == "mfma":
+        real = _lib.lib().mdm_last_gemm_kernel()   # the kernel that actually ran (name as rocprofv3 prints it)
+        if real:
+            name = real.decode() + (name[name.index(" M="):] if " M=" in name else "")
+    _prof.append((kind, name, work, e0, e1))
     return r
 
 
-def profile_end(peak_tflops):
-    """-> the ``roofline`` object of bench.py for the dominant kernel = the one that executes the most algorithmic
-    FLOPs of the step (the 3x3 forward / input-gradient GEMM; it is also first by total time in the rocprofv3
-    statistics, but only by a hair over the 1x1 kernel, so ranking by time flipped between runs)."""
+def profile_end(peak_tflops, peak_gbs=8000.0):
+    """-> the ``roofline`` object of bench.py.  The named kernel is the GEMM-class kernel with the LARGEST TOTAL TIME in
+    the step; ``gemm_weighted`` is the FLOP-weighted figure over every GEMM-class launch; ``hbm_kernels`` holds the
+    streaming kernels as algorithmic GB/s against the HBM peak."""
     global _prof
     rec, _prof = _prof, None
     torch.cuda.synchronize()
-    agg = {}
-    for name, flops, e0, e1 in rec:
-        a = agg.setdefault(name, [0, 0.0, 0.0])
+    agg, hbm = {}, {}
+    for kind, name, work, e0, e1 in rec:
+        a = (hbm if kind == "hbm" else agg).setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
-        a[1] += flops
+        a[1] += work
         a[2] += e0.elapsed_time(e1) * 1e-3
     if not agg:
         return None
     table = {k: {"launches": v[0], "alg_tflop": round(v[1] / 1e12, 3), "time_ms": round(v[2] * 1e3, 3),
                  "tflops": round(v[1] / v[2] / 1e12, 1)} for k, v in agg.items()}
-    dom = max(agg, key=lambda k: agg[k][1])
+    dom = max(agg, key=lambda k: agg[k][2])
     n, fl, t = agg[dom]
     ach = fl / t / 1e12
+    tot_f, tot_t = sum(v[1] for v in agg.values()), sum(v[2] for v in agg.values())
     return {
         "bound": "mfma", "achieved": round(ach, 1), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(ach / peak_tflops, 4),
-        "traffic": None, "kernel": dom, "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4),
-        "alg_gflop_per_launch": round(fl / n / 1e9, 2), "all_gemm_kernels": table,
+        "traffic": None, "kernel": dom, "dominant_by": "largest total time among the GEMM-class kernels of one step",
+        "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4),
+        "alg_gflop_per_launch": round(fl / n / 1e9, 2),
+        "gemm_weighted": {"alg_tflop": round(tot_f / 1e12, 2), "time_ms": round(tot_t * 1e3, 2),
+                          "tflops": round(tot_f / tot_t / 1e12, 1), "frac": round(tot_f / tot_t / 1e12 / peak_tflops, 4)},
+        "all_gemm_kernels": table,
+        "hbm_kernels": {k: {"launches": v[0], "alg_gb": round(v[1] / 1e9, 3), "time_ms": round(v[2] * 1e3, 3),
+                            "gb_per_s": round(v[1] / v[2] / 1e9, 1), "frac_of_peak": round(v[1] / v[2] / 1e9 / peak_gbs, 4)}
+                        for k, v in hbm.items()},
     }
 
 
@@ -494,11 +525,11 @@ class GroupNormFn(torch.autograd.Function):
         stats = torch.empty((N, groups, 2), dtype=torch.float32, device=x.device)
         coef = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
         ws = _gn_ws(N, HW, C, groups, x.device)
-        _lib.check(
+        _prof_wrap("group_norm fwd (HW=%d)" % HW, 2.0 * x.numel() * x.element_size(), lambda: _lib.check(
             _lib.lib().mdm_gn_fwd(_p(x), _p(g32), _p(b32), _p(film), _p(y), _p(stats), _p(coef), _p(ws), N, HW, C,
                                   groups, float(eps), act, _dt(x), _stream()),
             "mdm_gn_fwd",
-        )
+        ), kind="hbm")
         ctx.save_for_backward(x, gamma, beta, film, stats, coef)
         ctx.groups, ctx.act = groups, act
         ctx.passthrough = passthrough
@@ -523,11 +554,11 @@ class GroupNormFn(torch.autograd.Function):
         dbeta = sb if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
         dfilm = torch.empty_like(film) if film is not None else None
         ws = _gn_ws(N, HW, C, ctx.groups, x.device)
-        _lib.check(
+        _prof_wrap("group_norm bwd (HW=%d)" % HW, (4.0 if dres is not None else 3.0) * x.numel() * x.element_size(), lambda: _lib.check(
             _lib.lib().mdm_gn_bwd(_p(dy), _p(x), _p(g32), _p(b32), _p(film), _p(stats), _p(coef), _p(dres), _p(dx), _p(dgamma),
                                   _p(dbeta), _p(dfilm), _p(ws), N, HW, C, ctx.groups, ctx.act, 1 if sunk else 0, _dt(x), _stream()),
             "mdm_gn_bwd",
-        )
+        ), kind="hbm")
         if sunk:
             _grad_sink.ready(gamma)
             _grad_sink.ready(beta)
@@ -601,10 +632,10 @@ class AttentionFn(torch.autograd.Function):
         lse_s = torch.empty((B, heads, L), dtype=torch.float32, device=qkv.device) if keep else None
         lse_c = torch.empty((B, heads, L), dtype=torch.float32, device=qkv.device) if (keep and kvc is not None) else None
         oc = torch.empty_like(out) if kvc is not None else None   # also the kernel's staging buffer for the cross part
-        _lib.check(
+        _prof_wrap("attn_fwd_kernel<d=%d> L=%d" % (d, L), 4.0 * B * heads * L * (L + S) * d, lambda: _lib.check(
             _lib.lib().mdm_attn_fwd(_p(qkv), _p(kvc), _p(m32), _p(out), _p(oc), _p(lse_s), _p(lse_c), B, L, S, heads, d, _dt(qkv), _stream()),
             "mdm_attn_fwd",
-        )
+        ), kind="attn")
         ctx.save_for_backward(qkv, kvc, m32, out, oc, lse_s, lse_c)
         ctx.heads = heads
         return out
@@ -623,11 +654,11 @@ class AttentionFn(torch.autograd.Function):
         dkvc = torch.empty_like(kvc) if kvc is not None else None
         delta_s = torch.empty_like(lse_s)
         delta_c = torch.empty_like(lse_c) if kvc is not None else None
-        _lib.check(
+        _prof_wrap("attn_bwd (delta + dq + dkv kernels)<d=%d> L=%d" % (d, L), 8.0 * B * heads * L * (L + S) * d, lambda: _lib.check(
             _lib.lib().mdm_attn_bwd(_p(qkv), _p(kvc), _p(m32), _p(out), _p(oc), _p(dout), _p(lse_s), _p(lse_c), _p(delta_s),
                                     _p(delta_c), _p(dqkv), _p(dkvc), B, L, S, heads, d, _dt(qkv), _stream()),
             "mdm_attn_bwd",
-        )
+        ), kind="attn")
         return dqkv, dkvc, None, None, None
 
 
@@ -700,7 +731,8 @@ class ConcatFn(torch.autograd.Function):
         C1, C2 = a.shape[-1], b.shape[-1]
         M = a.numel() // C1
         out = torch.empty(a.shape[:-1] + (C1 + C2,), dtype=a.dtype, device=a.device)
-        _lib.check(_lib.lib().mdm_concat(_p(a), _p(b), _p(out), M, C1, C2, 0, _dt(a), _stream()), "mdm_concat")
+        _prof_wrap("concat", 2.0 * out.numel() * out.element_size(),
+                   lambda: _lib.check(_lib.lib().mdm_concat(_p(a), _p(b), _p(out), M, C1, C2, 0, _dt(a), _stream()), "mdm_concat"), kind="hbm")
         ctx.C1, ctx.C2 = C1, C2
         return out
 
@@ -1054,10 +1086,11 @@ def sumsq(flat_f32, out=None):
 def adamw_ema_step(p, g, m, v, ema, gnorm_sq, lr, beta1, beta2, eps, weight_decay, step, clip, ema_decay, zero_grad=True):
     """one fused clip + AdamW + EMA (+ zero-grad) pass over flat fp32 arenas; invalidates the packed-weight cache"""
     _require_gpu(p)
-    _lib.check(
+    nbytes = 4.0 * p.numel() * ((4 if ema is None else 5) + (3 if ema is None else 4) + (1 if zero_grad else 0))
+    _prof_wrap("adamw_ema_step", nbytes, lambda: _lib.check(
         _lib.lib().mdm_adamw_ema_step(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(gnorm_sq), p.numel(), float(lr), float(beta1),
                                       float(beta2), float(eps), float(weight_decay), int(step), float(clip), float(ema_decay),
                                       1 if zero_grad else 0, _stream()),
         "mdm_adamw_ema_step",
-    )
+    ), kind="hbm")
     invalidate_packed_weights()

@@ -7,12 +7,11 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ml-mdm_amd"))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch  # noqa: E402
 
 import mdm_hip  # noqa: E402
-import unet_oracle as O  # noqa: E402
 from mdm_hip import configs, diffusion, samplers  # noqa: E402
+from mdm_hip.testing import randomize_zero_params  # noqa: E402
 
 
 def main():
@@ -32,7 +31,7 @@ def main():
         net, side = mdm_hip.NestedUNet(3, 3, cfg), 256 if which == "nested256" else 1024
         pipe = diffusion.NestedDiffusion(net, diffusion.NestedDiffusionConfig(sampler_config=sc, use_vdm_loss_weights=False,
                                                                               use_double_loss=True, no_use_residual=True))
-    net.load_state_dict(O.randomize_zero_params(net.state_dict(), seed=1))
+    net.load_state_dict(randomize_zero_params(net.state_dict(), seed=1))
     pipe = pipe.to(dev)
     if use_graph:
         from mdm_hip.graph import GraphedDenoiser
