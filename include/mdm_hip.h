@@ -68,6 +68,14 @@ int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, float* ws, int 
                    int Wo, int Cout, int ksize, int stride, int dtype, void* stream);
 int mdm_conv_wgrad_reduce(const float* ws, float* dw_oihw, float* dbias, const void* dy, int M, int Cin, int Cout,
                           int ksize, int accumulate, int dtype, void* stream);
+/* Grouped weight gradient of `groups` (<= 32) same-shape 1x1 convolutions / linear layers, bf16: ONE launch, no split
+ * of the pixel reduction, results ADDED into dw[g] (Cout, Cin) / dbias[g] (Cout, may be NULL) -- the parameters' slots
+ * of a flat gradient arena.  x[g] [M, Cin], dy[g] [M, Cout]; the pointer arrays are HOST arrays of device pointers.
+ * mdm_conv_wgrad_group_plan: *tile_out = 128 / 256 when grouping fills the chip without a split, 0 when the caller
+ * should launch the problems one by one (mdm_conv_wgrad). */
+int mdm_conv_wgrad_group_plan(int M, int Cout, int K, int dtype, int groups, int* tile_out);
+int mdm_conv_wgrad_grouped(const void* const* x, const void* const* dy, float* const* dw, float* const* dbias,
+                           int groups, int M, int Cin, int Cout, int dtype, void* stream);
 int mdm_colsum_plan(int M, int C, int* nblocks, size_t* ws_bytes);
 int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulate, int dtype, void* stream);
 

