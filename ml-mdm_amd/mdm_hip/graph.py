@@ -176,7 +176,11 @@ class GraphedSampler:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             body()
-        ent = dict(graph=graph, x=x_static, ce=ce_s, cs=cs_s, cm=cm_s, idx=idx, rng=rng, n=n_steps)
+        # everything the graph reads by raw pointer must outlive it: the schedule tables too (they are locals of this
+        # function; once freed, a later allocation reuses their memory and the replayed index_select reads garbage
+        # indices -> out-of-bounds gather)
+        ent = dict(graph=graph, x=x_static, ce=ce_s, cs=cs_s, cm=cm_s, idx=idx, rng=rng, n=n_steps,
+                   keep=(tab_t, tab_s, tab_gate))
         self._graphs[key] = ent
         return ent
 

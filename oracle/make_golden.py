@@ -232,8 +232,58 @@ def full_size_golden():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def reference_bf16_error():
+    """The bar the bf16 mode is held to: the REFERENCE's own error when it runs under
+    torch.autocast(bfloat16) -- what its `fp16: 1` training does (trainer.py:29-30) -- against its fp32 run, per parity
+    case: rel-L2 of every output, and the aggregate rel-L2 of all parameter gradients (through the golden probes for the
+    full-size cases).  CPU autocast; written to tests/golden/reference_bf16_error.pt."""
+    import unet_oracle as O
+
+    R = ref_import.load()
+    res = {}
+
+    def build(cfg, sd):
+        rcfg = to_ref_cfg(R, cfg)
+        ref = (R.nested_unet.NestedUNet if hasattr(rcfg, "inner_config") else R.unet.UNet)(3, 3, rcfg)
+        ref.load_state_dict(sd, strict=True)
+        return ref
+
+    for name in PC.CASES:
+        _, cfg, sd = PC.build_module(name)
+        ref, inp = build(cfg, sd), PC.inputs(name)
+        o32 = PC.as_list(ref(inp["x"], inp["times"], inp["cond"], inp["mask"]))
+        PC.loss_of(o32, inp["gys"]).backward()
+        g32 = {k: p.grad.clone() for k, p in ref.named_parameters()}
+        ref.zero_grad(set_to_none=True)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            o16 = PC.as_list(ref(inp["x"], inp["times"], inp["cond"], inp["mask"]))
+        PC.loss_of([o.float() for o in o16], inp["gys"]).backward()
+        num = sum(float((p.grad.double() - g32[k].double()).pow(2).sum()) for k, p in ref.named_parameters())
+        den = sum(float(g.double().pow(2).sum()) for g in g32.values())
+        res[name] = {"fwd": [O.rel_l2(a.float(), b) for a, b in zip(o16, o32)], "grad_agg": (num / den) ** 0.5}
+        print(name, res[name], flush=True)
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "full_size.pt"), weights_only=False)
+    for name in PC.FULL:
+        _, sd = PC.full_module(name)
+        ref, inp = build(PC.full_cfg(name), sd), PC.full_inputs(name)
+        with_grad = "grad_norm" in gold[name]
+        with torch.no_grad():
+            o32 = PC.as_list(ref(inp["x"], inp["times"], inp["cond"], inp["mask"]))
+        with torch.set_grad_enabled(with_grad), torch.autocast("cpu", dtype=torch.bfloat16):
+            o16 = PC.as_list(ref(inp["x"], inp["times"], inp["cond"], inp["mask"]))
+        res[name] = {"fwd": [O.rel_l2(a.float(), b) for a, b in zip(o16, o32)]}
+        if with_grad:
+            PC.loss_of([o.float() for o in o16], inp["gys"]).backward()
+            g = gold[name]
+            num = sum((float((p.grad.double() * PC.probe_for(k, p.grad.shape)).sum()) - g["grad_probe"][k]) ** 2
+                      for k, p in ref.named_parameters())
+            res[name]["grad_agg"] = (num / sum(n * n for n in g["grad_norm"].values())) ** 0.5
+        print(name, res[name], flush=True)
+    torch.save(res, os.path.join(ROOT, "tests", "golden", "reference_bf16_error.pt"))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mini", "host", "pipeline", "full"]
+    which = sys.argv[1:] or ["mini", "host", "pipeline", "full", "bf16"]
     if "mini" in which:
         main()
     if "host" in which:
@@ -242,3 +292,5 @@ if __name__ == "__main__":
         sampling_golden()
     if "full" in which:
         full_size_golden()
+    if "bf16" in which:
+        reference_bf16_error()

@@ -198,5 +198,6 @@ def test_gpu_get_loss_equals_cpu_formulation():
             out[0].sum().backward()
             w = pipe.get_model().vision_model.w
             res.append((out[0].detach().cpu(), out[2].detach().cpu(), out[4].detach().cpu(), w.grad.detach().cpu().clone()))
-        for a, b in zip(res[1], res[0]):
+        for a, b in zip(res[1][:3], res[0][:3]):
             assert relerr(a, b) < 1e-5
+        assert relerr(res[1][3], res[0][3]) < 2e-4   # one scalar = a sum over every pixel: summation order

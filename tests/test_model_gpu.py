@@ -3,9 +3,10 @@
   * the golden vectors produced by the real reference (tests/golden/*.pt)
 
 Tolerances (rel-L2): fp32 mode outputs 1e-4, gradients 1e-3 (SURVEY.md section 8d parity gates;
-oracle fp32-vs-fp64 noise is ~1e-6).  bf16 mode: outputs 1.3e-2 -- the reference's own bf16-autocast
-forward error against fp64 on UNet-64 (SURVEY.md section 8c) -- and 3e-2 on the aggregate gradient;
-the measured values are printed (pytest -s / the captured-output section of a failure).
+oracle fp32-vs-fp64 noise is ~1e-6).  bf16 mode: every output and the aggregate parameter gradient must be
+at least as close to the fp32 reference as the REFERENCE's own bf16-autocast run of the same case
+(tests/golden/reference_bf16_error.pt, measured by oracle/make_golden.py on the real reference; 1.30e-2 for
+the UNet-64 forward, the figure SURVEY.md section 8c quotes).  Measured values are printed (pytest -s).
 """
 import os
 
@@ -17,6 +18,7 @@ import unet_oracle as O
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REF_BF16 = torch.load(os.path.join(GOLD, "reference_bf16_error.pt"))
 
 
 def hip_run(name, dtype, with_grad=True):
@@ -52,8 +54,8 @@ def test_fp32_matches_oracle_and_golden(name):
 
 @pytest.mark.parametrize("name", ["mini_unet", "mini_nested", "mini_nested2"])
 def test_bf16_close_to_oracle(name):
-    """bf16 mode vs the fp32 oracle: measured errors are printed; gates = the reference's own bf16-autocast forward
-    error (1.3e-2) and 3e-2 on the aggregate parameter gradient"""
+    """bf16 mode vs the fp32 oracle: measured errors are printed; gate = the reference's own bf16-autocast error on the
+    same case, per output and for the aggregate parameter gradient"""
     outs, grads = hip_run(name, torch.bfloat16)
     o_ref, g_ref = PC.oracle_run(name)
     errs = [O.rel_l2(a, b) for a, b in zip(outs, o_ref)]
@@ -61,8 +63,10 @@ def test_bf16_close_to_oracle(name):
     num = sum(float((grads[k].double().cpu() - g_ref[k].double()).pow(2).sum()) for k in g_ref)
     den = sum(float(g_ref[k].double().pow(2).sum()) for k in g_ref)
     agg = (num / den) ** 0.5
-    print("[bf16 %s] forward rel-L2 %s, aggregate gradient rel-L2 %.3e" % (name, ["%.3e" % e for e in errs], agg))
-    assert max(errs) < 1.3e-2 and agg < 3e-2
+    bar = REF_BF16[name]
+    print("[bf16 %s] forward rel-L2 %s (reference's own: %s), aggregate gradient rel-L2 %.3e (reference's own: %.3e)" % (
+        name, ["%.3e" % e for e in errs], ["%.3e" % e for e in bar["fwd"]], agg, bar["grad_agg"]))
+    assert all(e <= b for e, b in zip(errs, bar["fwd"])) and agg <= bar["grad_agg"]
 
 
 def test_forward_is_deterministic():
@@ -216,7 +220,8 @@ def test_full_size_architectures_match_reference(which):
       fp32 mode: every output (1e-4) and -- unet64 (B=2), nested256 -- every parameter gradient through its norm and a
                  seeded random projection (2e-3 of max(norm, floor));
       bf16 mode: forward error and the aggregate gradient error are PRINTED and gated at the reference's own
-                 bf16-autocast-vs-fp64 forward error, 1.3e-2; gradients at 3e-2.
+                 bf16-autocast error on the same case (tests/golden/reference_bf16_error.pt; 1.30e-2 for the UNet-64
+                 forward).
     nested1024 exercises the x / std input normalisation kernel of its 256 level (models/unet.py:871-872)."""
     gold = _full_gold(which)
     model, _ = PC.full_module(which)
@@ -248,15 +253,17 @@ def test_full_size_architectures_match_reference(which):
     for i, (o, gd) in enumerate(zip(out16, gold["outputs"])):
         st = max(1, o.shape[-1] // 64)
         errs.append(O.rel_l2(o.float()[..., ::st, ::st], gd["sub"]))
-    msg = "[bf16 %s] forward rel-L2 vs reference fp32: %s" % (which, ", ".join("%.3e" % e for e in errs))
+    bar = REF_BF16[which]
+    msg = "[bf16 %s] forward rel-L2 vs reference fp32: %s (reference's own bf16 error: %s)" % (
+        which, ", ".join("%.3e" % e for e in errs), ", ".join("%.3e" % e for e in bar["fwd"]))
     if with_grad:
         PC.loss_of(out16, inp["gys"]).backward()
         agg16 = _agg_grad_err({k: p.grad for k, p in model.named_parameters()}, gold)
-        msg += "; aggregate parameter-gradient error fp32 %.2e, bf16 %.3e" % (agg32, agg16)
+        msg += "; aggregate parameter-gradient error fp32 %.2e, bf16 %.3e (reference's own: %.3e)" % (agg32, agg16, bar["grad_agg"])
     print(msg)
-    assert max(errs) <= 1.3e-2, msg
+    assert all(e <= b for e, b in zip(errs, bar["fwd"])), msg
     if with_grad:
-        assert agg32 < 5e-4 and agg16 < 3e-2, msg
+        assert agg32 < 5e-4 and agg16 <= bar["grad_agg"], msg
 
 
 def test_config0_pipeline_at_full_size():
