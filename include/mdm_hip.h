@@ -60,6 +60,11 @@ const char* mdm_last_error(void);
  */
 int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int ksize, int Cin_pad,
                     int Cout_pad, int kblock_fwd, int kblock_dgrad, int dtype, void* stream);
+/* every kernel-layout weight of a model in ONE launch (they all go stale at each optimizer step).  `table`: DEVICE
+ * array of n 48-byte descriptors {const float* w; void* w_fwd; void* w_dgrad (or NULL); int Cout, Cin, taps (1 | 9),
+ * kblock_fwd, kblock_dgrad, first_block}; first_block = running sum of (Cout/32)*(Cin/32); total_blocks = the final
+ * sum.  Needs Cout % 32 == 0 and Cin % 32 == 0 (no channel padding) for every entry. */
+int mdm_pack_weights_multi(const void* table, int n, int total_blocks, int dtype, void* stream);
 int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const void* res, const void* aux, void* y,
                  void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride,
                  int transposed, int act, int kblock, int dtype, void* stream);

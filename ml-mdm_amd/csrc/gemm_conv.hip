@@ -1510,6 +1510,63 @@ __global__ __launch_bounds__(256) void pack_weight_tiled_kernel(const float* __r
   }
 }
 
+// All packed weights of a model in ONE launch (after an optimizer step every kernel-layout copy is stale: 227 launches
+// of ~7 us each for UNet-64 otherwise).  A descriptor per weight; block b finds its weight by binary search over the
+// prefix sums of the per-weight brick counts and then moves one [32 o][32 i][taps] brick exactly like the kernel above.
+struct PackDesc {
+  const float* w;   // reference layout (Cout, Cin, k, k)
+  void* wf;         // forward pack  [Cout][taps][Cin]  (block-major when kbf != 0)
+  void* wd;         // dgrad pack    [Cin][taps flipped][Cout], or null
+  int Cout, Cin, taps, kbf, kbd;
+  int first_block;  // prefix sum of (Cout / 32) * (Cin / 32)
+};
+
+template <typename T, int TAPS>
+__device__ __forceinline__ void pack_brick(const PackDesc& d, int brick, float (*tile)[32 * 9 + 1]) {
+  const int ibn = d.Cin / 32;
+  const int ib = (brick % ibn) * 32, ob = (brick / ibn) * 32;
+  const int tid = threadIdx.x;
+  const int Cin = d.Cin, Cout = d.Cout;
+  for (int e = tid; e < 32 * 32 * TAPS; e += 256) {
+    const int ol = e / (32 * TAPS), r = e - ol * (32 * TAPS);
+    tile[ol][r] = d.w[((size_t)(ob + ol) * Cin + ib) * TAPS + r];
+  }
+  __syncthreads();
+  const size_t Kf = (size_t)TAPS * Cin, Kd = (size_t)TAPS * Cout;
+  T* wf = reinterpret_cast<T*>(d.wf);
+  T* wd = reinterpret_cast<T*>(d.wd);
+  for (int e = tid; e < 32 * TAPS * 32; e += 256) {
+    const int il = e & 31, rest = e >> 5;
+    const int tp = rest % TAPS, ol = rest / TAPS;
+    const int i = ib + il;
+    const size_t kpos = d.kbf ? (size_t)(i / d.kbf) * TAPS * d.kbf + (size_t)tp * d.kbf + (i % d.kbf) : (size_t)tp * Cin + i;
+    wf[(size_t)(ob + ol) * Kf + kpos] = from_f32<T>(tile[ol][il * TAPS + tp]);
+  }
+  if (wd) {
+    for (int e = tid; e < 32 * TAPS * 32; e += 256) {
+      const int ol = e & 31, rest = e >> 5;
+      const int tp = rest % TAPS, il = rest / TAPS;
+      const int o = ob + ol;
+      const size_t kpos = d.kbd ? (size_t)(o / d.kbd) * TAPS * d.kbd + (size_t)tp * d.kbd + (o % d.kbd) : (size_t)tp * Cout + o;
+      wd[(size_t)(ib + il) * Kd + kpos] = from_f32<T>(tile[ol][il * TAPS + (TAPS - 1 - tp)]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackDesc* __restrict__ table, int n) {
+  __shared__ float tile[32][32 * 9 + 1];
+  int lo = 0, hi = n - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {   // last descriptor whose first_block <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = table[lo];
+  if (d.taps == 9) pack_brick<T, 9>(d, b - d.first_block, tile);
+  else pack_brick<T, 1>(d, b - d.first_block, tile);
+}
+
 // Column sums: out[c] = sum_m x[m, c]  (bias gradients).  Two deterministic stages: a
 // (column group) x (row slab) grid of partial sums, then a per-channel sum over the slabs.
 // A block is 8 chunk columns (128 bytes of a row) x 32 row lanes.
@@ -1905,6 +1962,19 @@ extern "C" int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, 
     hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(nb), dim3(256), 0, st, w_oihw, (float*)w_fwd, (float*)w_dgrad, Cout, Cin, taps, Cin_pad, Cout_pad, kblock_fwd, kblock_dgrad);
   else if (dtype == DT_BF16)
     hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(nb), dim3(256), 0, st, w_oihw, (bf16*)w_fwd, (bf16*)w_dgrad, Cout, Cin, taps, Cin_pad, Cout_pad, kblock_fwd, kblock_dgrad);
+  else MDM_CHECK_ARG(false);
+  MDM_LAUNCH_STATUS();
+}
+
+// table: DEVICE array of n descriptors {const float* w; void* w_fwd; void* w_dgrad; int Cout, Cin, taps, kblock_fwd,
+// kblock_dgrad, first_block} (48 bytes each, first_block = prefix sum of (Cout/32)*(Cin/32)); every weight must satisfy
+// Cout % 32 == 0 and Cin % 32 == 0 (no channel padding).  total_blocks = the sum of all brick counts.
+extern "C" int mdm_pack_weights_multi(const void* table, int n, int total_blocks, int dtype, void* stream) {
+  MDM_CHECK_ARG(table && n > 0 && total_blocks > 0);
+  static_assert(sizeof(PackDesc) == 48, "descriptor layout is part of the ABI");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == DT_F32) hipLaunchKernelGGL(pack_weights_multi_kernel<float>, dim3(total_blocks), dim3(256), 0, st, (const PackDesc*)table, n);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_weights_multi_kernel<bf16>, dim3(total_blocks), dim3(256), 0, st, (const PackDesc*)table, n);
   else MDM_CHECK_ARG(false);
   MDM_LAUNCH_STATUS();
 }

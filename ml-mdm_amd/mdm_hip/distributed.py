@@ -13,7 +13,13 @@ torch DDP's reducer with a design sized for 8 x MI355X on point-to-point xGMI li
     most of backward is still running;
   * a bucket's all-reduce is issued from a post-accumulate-grad hook as soon as its last
     gradient is ready, asynchronously on RCCL's own stream; ``finish()`` joins before the
-    optimizer.  Optional bf16 wire format halves the bytes.
+    optimizer.  Optional bf16 wire format halves the bytes;
+  * the LAST bucket (the first layers of the network: their gradients arrive when backward ends, so
+    nothing is left to hide its all-reduce behind) is kept small (``tail_mb``, default 8 MiB): the
+    exposed tail of the communication is one sub-millisecond collective, not a 256 MiB one.
+
+Unmeasured on hardware: the build environment exposes one GPU, so the 1 -> 8 scaling curve is the
+driver's to measure; the code path is exercised by gloo world-2 tests on CPU and a 2-rank shared-GPU test.
 """
 import os
 from datetime import timedelta
@@ -59,7 +65,7 @@ def init_distributed_singlenode(timeout: int = 0, backend: str = None):
 
 
 class GradReducer:
-    def __init__(self, params, bucket_mb: float = 256.0, wire_dtype: torch.dtype = None, group=None):
+    def __init__(self, params, bucket_mb: float = 256.0, wire_dtype: torch.dtype = None, group=None, tail_mb: float = 8.0):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -70,10 +76,21 @@ class GradReducer:
         # arena order = reverse registration order ~ the order backward produces gradients
         order = list(reversed(self.params))
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        tail = min(int(tail_mb * (1 << 20) / 4), cap)
+        # index of the first parameter of the tail bucket: the longest suffix of `order` that fits tail_mb
+        tail_from, acc = len(order), 0
+        for i in range(len(order) - 1, -1, -1):
+            acc += order[i].numel()
+            if acc > tail:
+                break
+            tail_from = i
         self.buckets = []          # (start, end)
         self._bucket_of = {}
         off = b_start = 0
-        for p in order:
+        for i, p in enumerate(order):
+            if i == tail_from and off > b_start:
+                self.buckets.append((b_start, off))
+                b_start = off
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             self._bucket_of[p] = len(self.buckets)

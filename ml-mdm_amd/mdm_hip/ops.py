@@ -288,11 +288,15 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
     cin_pad, cout_pad = _round_up(cin, epv), _round_up(cout, epv)
     taps = ks * ks
     w32 = _c(weight.detach().float())
-    wf = torch.empty(cout_pad * taps * cin_pad, dtype=dtype, device=weight.device)
     need_d = cin_pad == cin
-    wd = torch.empty(cin * taps * cout_pad, dtype=dtype, device=weight.device) if need_d else None
-    if cout_pad != cout:
-        wf.zero_()
+    prev = ent[key][1] if key in ent else None   # re-pack into the same buffers: their addresses stay valid (repack_all table)
+    if prev is not None and prev[0].numel() == cout_pad * taps * cin_pad and prev[0].device == weight.device:
+        wf, wd = prev[0], prev[1]
+    else:
+        wf = torch.empty(cout_pad * taps * cin_pad, dtype=dtype, device=weight.device)
+        wd = torch.empty(cin * taps * cout_pad, dtype=dtype, device=weight.device) if need_d else None
+        if cout_pad != cout:
+            wf.zero_()
     # 3x3: channel-block-major reduction order whenever the channel count is a multiple of the k-tile
     bk = 32 if dtype == torch.float32 else 64
     kbf = bk if (ks == 3 and cin_pad % bk == 0) else 0
@@ -311,6 +315,50 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
     val = (wf, wd, bp, cin_pad, cout_pad, kbf, kbd)
     ent[key] = (ver, val)
     return val
+
+
+_multi_tables = {}   # dtype -> (signature, device table, n, total blocks)
+
+
+def repack_all(dtype: torch.dtype):
+    """Refresh EVERY cached kernel-layout weight of ``dtype`` in one launch (C ABI mdm_pack_weights_multi) -- call right
+    after an optimizer step that invalidated them.  Weights the tiled pack cannot express (channel padding, counts not
+    a multiple of 32: the stem and the head) stay stale and are re-packed on their next use as before."""
+    import numpy as np
+
+    items = []
+    for wref, ent in _wcache.values():
+        w = wref()
+        if w is None or dtype not in ent or not w.is_cuda:
+            continue
+        ver, val = ent[dtype]
+        wf, wd, bp, cin_pad, cout_pad, kbf, kbd = val
+        cout, cin = w.shape[0], w.shape[1]
+        if cin_pad != cin or cout_pad != cout or cin % 32 or cout % 32 or w.dtype != torch.float32 or not w.is_contiguous():
+            continue
+        taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
+        if taps not in (1, 9):
+            continue
+        items.append((w, ent, ver, val, cout, cin, taps, kbf, kbd))
+    if not items:
+        return
+    sig = tuple((w.data_ptr(), val[0].data_ptr(), 0 if val[1] is None else val[1].data_ptr()) for w, _, _, val, *_ in items)
+    tab = _multi_tables.get(dtype)
+    if tab is None or tab[0] != sig:
+        desc = np.zeros(len(items), dtype=[("w", "u8"), ("wf", "u8"), ("wd", "u8"), ("cout", "i4"), ("cin", "i4"),
+                                           ("taps", "i4"), ("kbf", "i4"), ("kbd", "i4"), ("first", "i4")])
+        first = 0
+        for i, (w, _, _, val, cout, cin, taps, kbf, kbd) in enumerate(items):
+            desc[i] = (w.data_ptr(), val[0].data_ptr(), 0 if val[1] is None else val[1].data_ptr(), cout, cin, taps, kbf, kbd, first)
+            first += (cout // 32) * (cin // 32)
+        assert desc.dtype.itemsize == 48
+        dev_tab = torch.from_numpy(desc.view(np.uint8).copy()).to(items[0][0].device)
+        tab = (sig, dev_tab, len(items), first)
+        _multi_tables[dtype] = tab
+    _lib.check(_lib.lib().mdm_pack_weights_multi(_p(tab[1]), tab[2], tab[3], F32 if dtype == torch.float32 else BF16, _stream()),
+               "mdm_pack_weights_multi")
+    for w, ent, ver, val, *_ in items:
+        ent[dtype] = ((w._version, ver[1], w.data_ptr(), _pack_epoch), val)
 
 
 # --------------------------------------------------------------------------------------

@@ -100,6 +100,7 @@ class TrainStep:
             ops.adamw_ema_step(self.flat_p, self.reducer.flat, self.m, self.v, self.flat_ema, self.gnorm_sq, self.lr,
                                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps, self.clip_norm,
                                self.ema_decay, zero_grad=True)
+            ops.repack_all(torch.bfloat16 if self.bf16 else torch.float32)   # one launch instead of one per weight
             return loss_val
         gnorm = torch.linalg.vector_norm(self.reducer.flat)
         scale = torch.clamp(self.clip_norm / (gnorm + 1e-6), max=1.0)

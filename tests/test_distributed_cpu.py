@@ -81,6 +81,83 @@ def test_grad_reducer_gloo_world2(tmp_path, bucket_mb, wire):
         assert got["nb"] > 1  # several buckets were in flight during backward
 
 
+class _SinkLinear(torch.autograd.Function):
+    """stands in for the HIP ops under a gradient sink: the weight / bias gradients are ADDED into the reducer's arena
+    slots from inside backward, reported with ready(), and autograd gets None back (mdm_hip.ops.ConvFn.backward)"""
+    sink = None
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w, b)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        s = _SinkLinear.sink
+        s.slot(w).add_(dy.t() @ x)
+        s.slot(b).add_(dy.sum(0))
+        s.ready(w)
+        s.ready(b)
+        return dy @ w, None, None
+
+
+def _sink_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml-mdm_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mdm_hip import distributed as md
+
+    md.init_distributed_singlenode(backend="gloo")
+    model = _model(seed=0)
+    lin = [m for m in model if isinstance(m, nn.Linear)]
+    red = md.GradReducer(list(model.parameters()), bucket_mb=0.002, tail_mb=0.005)
+    _SinkLinear.sink = red
+
+    def fwd(x):
+        for i, m in enumerate(lin):
+            x = _SinkLinear.apply(x, m.weight, m.bias)
+            if i < len(lin) - 1:
+                x = torch.nn.functional.silu(x)
+        return x
+
+    g = torch.Generator().manual_seed(100)
+    x_all, y_all = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    xs, ys = x_all[rank::world], y_all[rank::world]
+    for step in range(2):               # two optimizer steps, each = one no_sync micro-step + one synchronised one
+        with red.no_sync():
+            ((fwd(xs) - ys) ** 2).mean().backward()
+        ((fwd(xs) - ys) ** 2).mean().backward()
+        red.finish()
+        flat = red.flat.clone()
+        red.zero_grad()
+    if rank == 0:
+        torch.save({"flat": flat, "nb": len(red.buckets), "last": red.buckets[-1]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sink_mode_with_accumulation_gloo_world2(tmp_path):
+    """the gradient-sink reporting path (ready() from inside backward, no autograd gradient) through no_sync
+    accumulation and several buckets incl. the small tail bucket: every bucket fires exactly once per synchronised
+    backward and finish() returns the rank average of the accumulated gradients"""
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_sink_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    model = _model(seed=0)
+    g = torch.Generator().manual_seed(100)
+    x_all, y_all = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    params = list(model.parameters())
+    gs = []
+    for r in range(2):
+        loss = ((model(x_all[r::2]) - y_all[r::2]) ** 2).mean()
+        gs.append(torch.cat([t.reshape(-1) for t in reversed(torch.autograd.grad(loss, params))]))
+    expect = (2 * gs[0] + 2 * gs[1]) / 2
+    assert torch.allclose(got["flat"], expect, atol=1e-5 * float(expect.abs().max()))
+    assert got["nb"] > 2
+    s, e = got["last"]
+    assert (e - s) == 16 * 64 + 64   # the tail bucket holds exactly the first layer's parameters (<= tail_mb)
+
+
 def test_single_process_reducer_is_a_noop():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml-mdm_amd"))
     from mdm_hip import distributed as md

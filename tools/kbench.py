@@ -71,6 +71,20 @@ def main():
             t = timeit(lambda: ops._wgrad_launch(x, y, B, H, H, cin, Ho, Ho, cout, ks, stride))
             line += "  wgrad %7.3f ms %7.1f TF" % (t * 1e3, flops / t / 1e12)
         print(line, flush=True)
+    if what in ("grouped",):
+        G = int(os.environ.get("KB_GROUPS", "26"))
+        for name, H, cin, cout, ks, stride in SHAPES:
+            if ks != 1:
+                continue
+            M = B * H * H
+            xs = [torch.randn(M, cin, device=dev).to(DT) for _ in range(G)]
+            dys = [torch.randn(M, cout, device=dev).to(DT) for _ in range(G)]
+            dws = [torch.zeros(cout, cin, device=dev) for _ in range(G)]
+            dbs = [torch.zeros(cout, device=dev) for _ in range(G)]
+            t = timeit(lambda: ops.wgrad_grouped(xs, dys, dws, dbs), iters=5)
+            fl = 2.0 * G * M * cin * cout
+            t1 = timeit(lambda: [ops._wgrad_launch(xs[i].view(B, H, H, cin), dys[i].view(B, H, H, cout), B, H, H, cin, H, H, cout, 1, 1, out=dws[i], dbias=dbs[i]) for i in range(G)], iters=3)
+            print("%-22s grouped x%d %7.3f ms %7.1f TF   one-by-one (split + reduce) %7.3f ms %7.1f TF" % (name, G, t * 1e3, fl / t / 1e12, t1 * 1e3, fl / t1 / 1e12), flush=True)
     if what in ("attn", "all"):
         for L, d in ((1024, 64), (256, 96)):
             C = 8 * d
