@@ -81,6 +81,11 @@ int mdm_conv_wgrad_reduce(const float* ws, float* dw_oihw, float* dbias, const v
 int mdm_conv_wgrad_group_plan(int M, int Cout, int K, int dtype, int groups, int* tile_out);
 int mdm_conv_wgrad_grouped(const void* const* x, const void* const* dy, float* const* dw, float* const* dbias,
                            int groups, int M, int Cin, int Cout, int dtype, void* stream);
+/* y[g] [M, Cout] = x[g] [M, Cin] w_packed[g]^T + bias[g] for `groups` (<= 32) linear layers of ONE shape in one launch
+ * (bf16, Cin % 64 == 0): the key / value projections of the text states of every attention layer (unet.py:264).  HOST
+ * arrays of device pointers; bias may be NULL.  With the dgrad packs and the output gradients: the input gradients. */
+int mdm_linear_grouped(const void* const* x, const void* const* w_packed, const float* const* bias, void* const* y,
+                       int groups, int M, int Cin, int Cout, int dtype, void* stream);
 int mdm_colsum_plan(int M, int C, int* nblocks, size_t* ws_bytes);
 int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulate, int dtype, void* stream);
 
@@ -106,6 +111,16 @@ int mdm_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, fl
 /* ws: fp32 [ceil(R/64)][D][2] */
 int mdm_ln_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, float* dgamma,
                float* dbeta, float* ws, int R, int D, int accumulate, int dtype, void* stream);
+
+/* One input, L (<= 32) LayerNorms: every attention layer normalises the SAME text states with its own gamma / beta
+ * before its key / value projection (unet.py:263-264, 304).  mdm_ln_multi_fwd: statistics once, L affine outputs;
+ * mdm_ln_multi_bwd: dx = the SUM of the L input gradients, dgamma[l] / dbeta[l] (+)= by fp32 atomics (`accumulate` == 0
+ * zero-fills them first).  gamma / beta / y / dy / dgamma / dbeta are HOST arrays of device pointers.  D <= 4096. */
+int mdm_ln_multi_fwd(const void* x, const float* const* gamma, const float* const* beta, void* const* y, int L,
+                     float* stats, int R, int D, float eps, int dtype, void* stream);
+int mdm_ln_multi_bwd(const void* const* dy, const void* x, const float* const* gamma, const float* stats, void* dx,
+                     float* const* dgamma, float* const* dbeta, int L, int R, int D, int accumulate, int dtype,
+                     void* stream);
 
 /* ---- fused self + text cross attention ---------------------------------------------------
  * replaces SelfAttention.attention x2 + the sum (unet.py:276-307): einsum QK^T, fp32 softmax, einsum PV.

@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "common.hpp"
@@ -39,6 +40,7 @@ struct ConvArgs {
   int Ho, Wo, Cout;   // geometry of y
   int stride;
   int M, K;
+  int groups;         // grouped launches only (ConvGroup)
   int act;            // 0 none, 1 y=gelu(v), 2 y=v*gelu'(aux)
   int kblk;           // 3x3 k-order: 0 = tap-major (k = tap*Cin + cin); B = channel-block-major,
                       // k = (cin / B) * 9 * B + tap * B + cin % B with B = the k-tile (64 bf16 / 32 fp32)
@@ -356,10 +358,24 @@ __device__ __forceinline__ void sched_rows(std::integer_sequence<int, I...>) {
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)), ...);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs p) {
+// Grouped launch (GROUPED = true, 1x1 only): G problems of one shape (M, K, Cout) -- the text-state key / value
+// projections of every attention layer, unet.py:264 -- in ONE launch: tile t belongs to problem t / tiles_per_problem and
+// takes its operand / output pointers from the group table.  A single such problem (M = B * 32 text tokens) is 96-192
+// tiles of 128x128: a quarter of the chip, 28 us each for 31 layers.
+constexpr int CG_MAXG = 32;
+struct ConvGroup {
+  const void* x[CG_MAXG];
+  const void* w[CG_MAXG];
+  const float* bias[CG_MAXG];
+  void* y[CG_MAXG];
+};
+struct NoConvGroup {};
+
+template <int BM, int BN, int WM, int WN, int MODE, bool GROUPED = false>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs p, std::conditional_t<GROUPED, ConvGroup, NoConvGroup> gr) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type has no host-side counterpart: the host pass only needs the stub
   using T = bf16;
+  static_assert(!GROUPED || MODE == MODE_1x1, "grouped launches: 1x1 / linear only");
   constexpr int NT_ = WM * WN * 64;
   constexpr int RPP = NT_ / 8;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -378,7 +394,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   // Persistent blocks: block b works through output tiles b, b + G, b + 2G, ... (G = gridDim.x <= resident blocks);
   // within each group of G the XCD-aware remap keeps neighbouring tiles (shared operand panels) on one XCD's L2.
   const int tiles_n = (p.Cout + BN - 1) / BN;
-  const int tiles_total = ((p.M + BM - 1) / BM) * tiles_n;
+  const int tiles_per_problem = ((p.M + BM - 1) / BM) * tiles_n;
+  const int tiles_total = tiles_per_problem * (GROUPED ? p.groups : 1);
   const int G = gridDim.x;
   const int b_in_group = xcd_remap(blockIdx.x, G);
 
@@ -387,10 +404,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   const int lchunk = (tid & 7) ^ (lrow & 7);   // logical chunk this lane fetches (physical slot = tid & 7)
   const unsigned bias = MODE == MODE_3x3 ? (unsigned)(p.W + 1) * p.Cin * 2u : 0u;   // base shift that keeps the per-tap scalar offset non-negative
   unsigned a_voff[AJ], a_mask[AJ], b_voff[BJ];
-  int m0 = 0, n0 = 0;
+  int m0 = 0, n0 = 0, grp = 0;
+  char* a_base = const_cast<char*>(reinterpret_cast<const char*>(p.x)) - bias;
+  char* b_base = const_cast<char*>(reinterpret_cast<const char*>(p.w));
 #define MDM_TILE_SETUP(tile_)                                                                               \
   {                                                                                                         \
-    m0 = ((tile_) / tiles_n) * BM; n0 = ((tile_) % tiles_n) * BN;                                           \
+    int tl_ = (tile_);                                                                                      \
+    if constexpr (GROUPED) {                                                                                \
+      grp = tl_ / tiles_per_problem; tl_ -= grp * tiles_per_problem;                                        \
+      a_base = const_cast<char*>(reinterpret_cast<const char*>(gr.x[grp]));                                 \
+      b_base = const_cast<char*>(reinterpret_cast<const char*>(gr.w[grp]));                                 \
+    }                                                                                                       \
+    m0 = (tl_ / tiles_n) * BM; n0 = (tl_ % tiles_n) * BN;                                                   \
     _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                        \
       const int m = m0 + lrow + RPP * j;                                                                    \
       a_voff[j] = INVALID; a_mask[j] = 0u;                                                                  \
@@ -420,8 +445,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   }
   const unsigned a_bytes = (unsigned)p.N * p.H * p.W * p.Cin * 2u + bias;
   const unsigned b_bytes = (unsigned)p.Cout * p.K * 2u;
-  char* const a_base = const_cast<char*>(reinterpret_cast<const char*>(p.x)) - bias;
-  char* const b_base = const_cast<char*>(reinterpret_cast<const char*>(p.w));
   const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
   const int ntiles = p.K / 64;
 
@@ -530,7 +553,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
     __syncthreads();   // LDS is reused by the epilogue
     const int cur_m0 = m0, cur_n0 = n0;
     const int next = tile + G;
-    conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE>(p, acc, smem, cur_m0, cur_n0, [&]() {
+    ConvArgs pe = p;   // the epilogue's view of this tile's problem (the prefetch below already moves on to the next)
+    if constexpr (GROUPED) { pe.bias = gr.bias[grp]; pe.y = gr.y[grp]; }
+    conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE>(pe, acc, smem, cur_m0, cur_n0, [&]() {
       if (next < tiles_total) {
         MDM_TILE_SETUP(next);
         MDM_TILE_PROLOGUE();
@@ -1641,8 +1666,20 @@ static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
   ensure_dynamic_lds(kern, smem);
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
   const int resident = device_cus() * (WM * WN == 4 ? 2 : 1);   // persistent blocks: one (8 waves) or two (4 waves) per CU
-  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a, NoConvGroup{});
   MDM_NOTE_KERNEL("conv_gemm_bl_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, MODE);
+  MDM_LAUNCH_STATUS();
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_conv_bl_grouped(const ConvArgs& a, const ConvGroup& gr, hipStream_t st) {
+  constexpr int smem = 2 * (BM + BN) * 128;
+  auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE_1x1, true>;
+  ensure_dynamic_lds(kern, smem);
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN) * a.groups;
+  const int resident = device_cus() * (WM * WN == 4 ? 2 : 1);
+  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a, gr);
+  MDM_NOTE_KERNEL("conv_gemm_bl_kernel<%d, %d, %d, %d, %d, grouped>", BM, BN, WM, WN, MODE_1x1);
   MDM_LAUNCH_STATUS();
 }
 
@@ -1721,12 +1758,37 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
   ConvArgs a;
   a.x = x; a.w = w_packed; a.bias = bias; a.res = res; a.aux = aux; a.y = y; a.ypre = y_pre;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.stride = stride;
-  a.M = N * Ho * Wo; a.K = ksize * ksize * Cin; a.act = act;
+  a.M = N * Ho * Wo; a.K = ksize * ksize * Cin; a.act = act; a.groups = 0;
   const int bk = dtype == DT_F32 ? 32 : 64;
   MDM_CHECK_ARG(kblock == 0 || (ksize == 3 && kblock == bk && Cin % bk == 0));
   a.kblk = kblock;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return dtype == DT_F32 ? launch_conv_t<float>(a, ksize, transposed, st) : launch_conv_t<bf16>(a, ksize, transposed, st);
+}
+
+// y[g] [M, Cout] = x[g] [M, Cin] * w_packed[g]^T + bias[g] for `groups` (<= 32) linear layers of one shape, bf16, in ONE
+// launch.  The pointer arrays are HOST arrays of device pointers; bias may be NULL (no bias at all) .  Passing the
+// dgrad packs and the output gradients computes the input gradients of the same layers.  Cin % 64 == 0.
+extern "C" int mdm_linear_grouped(const void* const* x, const void* const* w_packed, const float* const* bias,
+                                  void* const* y, int groups, int M, int Cin, int Cout, int dtype, void* stream) {
+  MDM_CHECK_ARG(x && w_packed && y && groups >= 1 && groups <= CG_MAXG);
+  MDM_CHECK_ARG(dtype == DT_BF16 && Cin % 64 == 0 && Cout % 8 == 0 && M > 0);
+  ConvArgs a = {};
+  a.N = M; a.H = 1; a.W = 1; a.Cin = Cin; a.Ho = 1; a.Wo = 1; a.Cout = Cout; a.stride = 1;
+  a.M = M; a.K = Cin; a.act = 0; a.kblk = 0; a.groups = groups;
+  MDM_CHECK_ARG((size_t)M * Cin * 2 <= 0x7F000000u && (size_t)Cout * Cin * 2 <= 0x7F000000u);
+  ConvGroup gr = {};
+  for (int g = 0; g < groups; ++g) {
+    MDM_CHECK_ARG(x[g] && w_packed[g] && y[g]);
+    gr.x[g] = x[g]; gr.w[g] = w_packed[g]; gr.bias[g] = bias ? bias[g] : nullptr; gr.y[g] = y[g];
+  }
+  a.x = gr.x[0]; a.w = gr.w[0]; a.y = gr.y[0];
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // tile by the same cost model as a single problem of groups x M rows
+  const int code = conv_tile_code(M * groups, Cout, DT_BF16);
+  if (code == 256256) return launch_conv_bl_grouped<256, 256, 2, 4>(a, gr, st);
+  if (code == 256192) return launch_conv_bl_grouped<256, 192, 2, 4>(a, gr, st);
+  return launch_conv_bl_grouped<128, 128, 2, 2>(a, gr, st);
 }
 
 // workspace size (bytes) the caller must provide to mdm_conv_wgrad

@@ -636,6 +636,95 @@ __global__ void ln_bwd_param_final_kernel(const float* __restrict__ part, float*
   dbeta[i] = accumulate ? dbeta[i] + b : b;
 }
 
+// ---------------------------------------------------------------------------------
+// One input, L LayerNorms (different gamma / beta): every attention layer normalises the SAME text states before its
+// key / value projection (unet.py:263-264, 304).  Statistics once per row; L affine outputs; the backward sums the L
+// input gradients and emits the L parameter gradients.
+// ---------------------------------------------------------------------------------
+constexpr int LN_MAXL = 32;
+struct LnGroup {
+  const float* gamma[LN_MAXL];
+  const float* beta[LN_MAXL];
+  void* y[LN_MAXL];          // forward outputs / backward: upstream gradients
+  float* dgamma[LN_MAXL];
+  float* dbeta[LN_MAXL];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_multi_fwd_kernel(const T* __restrict__ x, LnGroup g, int L, float* __restrict__ stats,
+                                                           int D, float eps) {
+  __shared__ float sh[4];
+  const size_t row = blockIdx.x;
+  const T* xr = x + row * D;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) s += to_f32(xr[i]);
+  const float mu = block_sum(s, sh) / (float)D;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) { const float d = to_f32(xr[i]) - mu; v += d * d; }
+  const float rstd = rsqrtf(block_sum(v, sh) / (float)D + eps);
+  if (threadIdx.x == 0) { stats[row * 2] = mu; stats[row * 2 + 1] = rstd; }
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float xh = (to_f32(xr[i]) - mu) * rstd;
+    for (int l = 0; l < L; ++l) reinterpret_cast<T*>(g.y[l])[row * D + i] = from_f32<T>(xh * g.gamma[l][i] + g.beta[l][i]);
+  }
+}
+
+// dx[row] = sum_l rstd * (g_l - mean(g_l) - xhat * mean(g_l * xhat)),  g_l = dy_l * gamma_l      (D <= 4096)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_multi_bwd_kernel(LnGroup g, int L, const T* __restrict__ x,
+                                                           const float* __restrict__ stats, T* __restrict__ dx, int D) {
+  __shared__ float sh[4];
+  const size_t row = blockIdx.x;
+  const float mu = stats[row * 2], rstd = stats[row * 2 + 1];
+  float xh[16], acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    xh[k] = i < D ? (to_f32(x[row * D + i]) - mu) * rstd : 0.f;
+    acc[k] = 0.f;
+  }
+  for (int l = 0; l < L; ++l) {
+    const T* dyr = reinterpret_cast<const T*>(g.y[l]) + row * D;
+    float gl[16];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      gl[k] = i < D ? to_f32(dyr[i]) * g.gamma[l][i] : 0.f;
+      s1 += gl[k]; s2 += gl[k] * xh[k];
+    }
+    s1 = block_sum(s1, sh) / (float)D;
+    s2 = block_sum(s2, sh) / (float)D;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] += gl[k] - s1 - xh[k] * s2;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < D) dx[row * D + i] = from_f32<T>(rstd * acc[k]);
+  }
+}
+
+// dgamma_l[i] += sum_r dy_l[r, i] * xhat[r, i], dbeta_l[i] += sum_r dy_l[r, i]: grid (D / 256, row slabs, L); one fp32
+// atomic pair per (slab, layer, column)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_multi_param_kernel(LnGroup g, const T* __restrict__ x, const float* __restrict__ stats,
+                                                             int R, int D, int rows_per_block) {
+  const int l = blockIdx.z;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= D) return;
+  const T* dy = reinterpret_cast<const T*>(g.y[l]);
+  float a = 0.f, b = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float gy = to_f32(dy[(size_t)r * D + i]);
+    a += gy * (to_f32(x[(size_t)r * D + i]) - stats[r * 2]) * stats[r * 2 + 1];
+    b += gy;
+  }
+  unsafeAtomicAdd(g.dgamma[l] + i, a);
+  unsafeAtomicAdd(g.dbeta[l] + i, b);
+}
+
 }  // namespace mdm
 
 using namespace mdm;
@@ -796,5 +885,46 @@ extern "C" int mdm_ln_bwd(const void* dy, const void* x, const float* gamma, con
     hipLaunchKernelGGL(ln_bwd_param_partial_kernel<bf16>, dim3((D + 255) / 256, nsl), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, stats, ws, R, D, rpb);
   } else MDM_CHECK_ARG(false);
   hipLaunchKernelGGL(ln_bwd_param_final_kernel, dim3((D + 255) / 256), dim3(256), 0, st, ws, dgamma, dbeta, nsl, D, accumulate);
+  MDM_LAUNCH_STATUS();
+}
+
+// ---- one input, L LayerNorms ------------------------------------------------------------------------------------------
+// gamma / beta / y / dy / dgamma / dbeta: HOST arrays of L (<= 32) device pointers.  stats [R][2] is shared.
+extern "C" int mdm_ln_multi_fwd(const void* x, const float* const* gamma, const float* const* beta, void* const* y, int L,
+                                float* stats, int R, int D, float eps, int dtype, void* stream) {
+  MDM_CHECK_ARG(x && gamma && beta && y && stats && L >= 1 && L <= LN_MAXL && R > 0 && D > 0);
+  LnGroup g = {};
+  for (int l = 0; l < L; ++l) { MDM_CHECK_ARG(gamma[l] && beta[l] && y[l]); g.gamma[l] = gamma[l]; g.beta[l] = beta[l]; g.y[l] = y[l]; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == DT_F32) hipLaunchKernelGGL(ln_multi_fwd_kernel<float>, dim3(R), dim3(256), 0, st, (const float*)x, g, L, stats, D, eps);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(ln_multi_fwd_kernel<bf16>, dim3(R), dim3(256), 0, st, (const bf16*)x, g, L, stats, D, eps);
+  else MDM_CHECK_ARG(false);
+  MDM_LAUNCH_STATUS();
+}
+
+// dx = sum over the L norms of their input gradients; dgamma[l] / dbeta[l] (+)= the parameter gradients (`accumulate`
+// == 0 zero-fills them first).  D <= 4096.
+extern "C" int mdm_ln_multi_bwd(const void* const* dy, const void* x, const float* const* gamma, const float* stats,
+                                void* dx, float* const* dgamma, float* const* dbeta, int L, int R, int D, int accumulate,
+                                int dtype, void* stream) {
+  MDM_CHECK_ARG(dy && x && gamma && stats && dx && dgamma && dbeta && L >= 1 && L <= LN_MAXL && R > 0 && D > 0 && D <= 4096);
+  LnGroup g = {};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int l = 0; l < L; ++l) {
+    MDM_CHECK_ARG(dy[l] && gamma[l] && dgamma[l] && dbeta[l]);
+    g.y[l] = const_cast<void*>(dy[l]); g.gamma[l] = gamma[l]; g.dgamma[l] = dgamma[l]; g.dbeta[l] = dbeta[l];
+    if (!accumulate) {
+      (void)hipMemsetAsync(dgamma[l], 0, (size_t)D * sizeof(float), st);
+      (void)hipMemsetAsync(dbeta[l], 0, (size_t)D * sizeof(float), st);
+    }
+  }
+  const int rpb = 64, nsl = (R + rpb - 1) / rpb;
+  if (dtype == DT_F32) {
+    hipLaunchKernelGGL(ln_multi_bwd_kernel<float>, dim3(R), dim3(256), 0, st, g, L, (const float*)x, stats, (float*)dx, D);
+    hipLaunchKernelGGL(ln_multi_param_kernel<float>, dim3((D + 255) / 256, nsl, L), dim3(256), 0, st, g, (const float*)x, stats, R, D, rpb);
+  } else if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(ln_multi_bwd_kernel<bf16>, dim3(R), dim3(256), 0, st, g, L, (const bf16*)x, stats, (bf16*)dx, D);
+    hipLaunchKernelGGL(ln_multi_param_kernel<bf16>, dim3((D + 255) / 256, nsl, L), dim3(256), 0, st, g, (const bf16*)x, stats, R, D, rpb);
+  } else MDM_CHECK_ARG(false);
   MDM_LAUNCH_STATUS();
 }

@@ -745,6 +745,126 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 
 
 # --------------------------------------------------------------------------------------
+# text key / value projections of ALL attention layers at once
+# --------------------------------------------------------------------------------------
+def _ptr_array(ts):
+    return (ctypes.c_void_p * len(ts))(*[_p(t) for t in ts])
+
+
+class TextKVFn(torch.autograd.Function):
+    """kvc_l = Linear_l(LayerNorm_l(cond)) for every attention layer l (reference unet.py:263-264, 304: each layer
+    normalises and projects the SAME text states).  Forward: one multi-LayerNorm launch + one grouped GEMM launch per
+    output width; backward: grouped input-gradient GEMMs, one multi-LayerNorm backward (which also sums the L gradients
+    of ``cond``), grouped weight gradients.  ~8 launches instead of ~8 per layer; bf16 only (the fp32 parity mode runs
+    the layers one by one)."""
+
+    @staticmethod
+    def forward(ctx, cond, eps, *params):
+        _require_gpu(cond)
+        cond = _c(cond)
+        B, S, D = cond.shape
+        R, L = B * S, len(params) // 4
+        lnw, lnb, ws, bs = params[0::4], params[1::4], params[2::4], params[3::4]
+        lib = _lib.lib()
+        g32 = [_c(t.detach().float()) for t in lnw]
+        b32 = [_c(t.detach().float()) for t in lnb]
+        cn = [torch.empty_like(cond) for _ in range(L)]
+        stats = torch.empty((R, 2), dtype=torch.float32, device=cond.device)
+        _lib.check(lib.mdm_ln_multi_fwd(_p(cond), _ptr_array(g32), _ptr_array(b32), _ptr_array(cn), L, _p(stats), R, D, float(eps),
+                                        _dt(cond), _stream()), "mdm_ln_multi_fwd")
+        groups = {}
+        for l, w in enumerate(ws):
+            groups.setdefault(w.shape[0], []).append(l)
+        ys = [None] * L
+        for cout, idx in groups.items():
+            packs = [packed_weight(ws[l], bs[l], cond.dtype) for l in idx]
+            for l in idx:
+                ys[l] = torch.empty((B, S, cout), dtype=cond.dtype, device=cond.device)
+            _prof_wrap("linear grouped x%d M=%d N=%d K=%d" % (len(idx), R, cout, D), 2.0 * len(idx) * R * cout * D, lambda: _lib.check(
+                lib.mdm_linear_grouped(_ptr_array([cn[l] for l in idx]), _ptr_array([pk[0] for pk in packs]),
+                                       _ptr_array([pk[2] for pk in packs]), _ptr_array([ys[l] for l in idx]), len(idx), R, D, cout,
+                                       _dt(cond), _stream()), "mdm_linear_grouped"))
+        ctx.save_for_backward(cond, stats, *cn, *params)
+        ctx.L, ctx.groups = L, groups
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        saved = ctx.saved_tensors
+        L, groups = ctx.L, ctx.groups
+        cond, stats, cn, params = saved[0], saved[1], saved[2:2 + L], saved[2 + L:]
+        lnw, lnb, ws, bs = params[0::4], params[1::4], params[2::4], params[3::4]
+        B, S, D = cond.shape
+        R = B * S
+        lib = _lib.lib()
+        dys = [_c(d) if d is not None else torch.zeros((B, S, ws[l].shape[0]), dtype=cond.dtype, device=cond.device)
+               for l, d in enumerate(dys)]
+        dcn = [torch.empty_like(cond) for _ in range(L)]
+        grads = [None] * (4 * L)
+        for cout, idx in groups.items():
+            packs = [packed_weight(ws[l], bs[l], cond.dtype) for l in idx]
+            _prof_wrap("linear grouped x%d M=%d N=%d K=%d" % (len(idx), R, D, cout), 2.0 * len(idx) * R * cout * D, lambda: _lib.check(
+                lib.mdm_linear_grouped(_ptr_array([dys[l] for l in idx]), _ptr_array([pk[1] for pk in packs]), None,
+                                       _ptr_array([dcn[l] for l in idx]), len(idx), R, cout, D, _dt(cond), _stream()),
+                "mdm_linear_grouped"))
+            # weight / bias gradients: one grouped launch, into the gradient arena when there is one
+            slots = [(_slot(ws[l]), _slot(bs[l])) for l in idx]
+            sunk = all(a is not None and b is not None for a, b in slots)
+            if sunk:
+                dws, dbs = [a for a, _ in slots], [b for _, b in slots]
+            else:
+                dws = [torch.zeros(ws[l].shape, dtype=torch.float32, device=cond.device) for l in idx]
+                dbs = [torch.zeros(bs[l].shape, dtype=torch.float32, device=cond.device) for l in idx]
+            xs2, dy2 = [cn[l].reshape(R, D) for l in idx], [dys[l].reshape(R, cout) for l in idx]
+
+            def go(xs2=xs2, dy2=dy2, dws=dws, dbs=dbs, idx=idx, sunk=sunk, cout=cout):
+                _prof_wrap("conv_wgrad grouped x%d M=%d N=%d K=%d" % (len(idx), R, cout, D), 2.0 * len(idx) * R * cout * D,
+                           lambda: wgrad_grouped(xs2, dy2, dws, dbs))
+                if sunk:
+                    for l in idx:
+                        _grad_sink.ready(ws[l])
+                        _grad_sink.ready(bs[l])
+
+            if sunk:
+                _off_critical_path(xs2 + dy2, go)
+            else:
+                go()
+                for k, l in enumerate(idx):
+                    grads[4 * l + 2], grads[4 * l + 3] = dws[k], dbs[k]
+        g32 = [_c(t.detach().float()) for t in lnw]
+        nslots = [(_slot(lnw[l]), _slot(lnb[l])) for l in range(L)]
+        nsunk = all(a is not None and b is not None for a, b in nslots)
+        if nsunk:
+            dgs, dbs_ = [a for a, _ in nslots], [b for _, b in nslots]
+        else:
+            dgs = [torch.empty(D, dtype=torch.float32, device=cond.device) for _ in range(L)]
+            dbs_ = [torch.empty(D, dtype=torch.float32, device=cond.device) for _ in range(L)]
+        dcond = torch.empty_like(cond)
+        _lib.check(lib.mdm_ln_multi_bwd(_ptr_array(dcn), _p(cond), _ptr_array(g32), _p(stats), _p(dcond), _ptr_array(dgs),
+                                        _ptr_array(dbs_), L, R, D, 1 if nsunk else 0, _dt(cond), _stream()), "mdm_ln_multi_bwd")
+        if nsunk:
+            for l in range(L):
+                _grad_sink.ready(lnw[l])
+                _grad_sink.ready(lnb[l])
+        else:
+            for l in range(L):
+                grads[4 * l], grads[4 * l + 1] = dgs[l], dbs_[l]
+        return (dcond, None) + tuple(grads)
+
+
+def text_kv_supported(cond, layers):
+    """the grouped path needs bf16 text states of a width the buffer-addressed GEMM takes"""
+    return cond.is_cuda and cond.dtype == torch.bfloat16 and cond.shape[-1] % 64 == 0 and 0 < len(layers) <= 32 and \
+        all(w.shape[0] % 64 == 0 for _, _, w, _ in layers)
+
+
+def text_kv(cond, layers, eps=1e-5):
+    """layers: [(ln_weight, ln_bias, weight, bias)] -> tuple of kvc tensors [B, S, Cout_l]"""
+    flat = [t for quad in layers for t in quad]
+    return TextKVFn.apply(cond, eps, *flat)
+
+
+# --------------------------------------------------------------------------------------
 # attention
 # --------------------------------------------------------------------------------------
 class AttentionFn(torch.autograd.Function):

@@ -137,6 +137,31 @@ class ResNet(nn.Module):
         return ops.conv(h, self.conv2.weight, self.conv2.bias, residual=shortcut)
 
 
+class TextStates:
+    """The text conditioning as the attention layers consume it: the projected states [B, S, D] plus, when they were
+    computed up front (bf16: one grouped launch for all layers, ops.text_kv), every layer's key / value projection.
+    Behaves like the plain tensor for the few things the callers do with it (batch slicing in the nested model)."""
+
+    def __init__(self, raw, kv=None):
+        self.raw, self.kv = raw, kv or {}
+
+    def __getitem__(self, idx):
+        return TextStates(self.raw[idx], {k: v[idx] for k, v in self.kv.items()})
+
+    @property
+    def shape(self):
+        return self.raw.shape
+
+    def clone(self):
+        return TextStates(self.raw.clone(), {k: v.clone() for k, v in self.kv.items()})
+
+    def copy_(self, other):
+        self.raw.copy_(other.raw)
+        for k, v in self.kv.items():
+            v.copy_(other.kv[k])
+        return self
+
+
 class SelfAttention(nn.Module):
     """2-D self attention + text cross attention + optional FFN (reference unet.py:241-313)."""
 
@@ -171,8 +196,12 @@ class SelfAttention(nn.Module):
         qkv = ops.conv(hn, self.qkv.weight, self.qkv.bias)
         kvc = None
         if self.cond_dim is not None and self.cond_dim > 0:
-            cn = ops.layer_norm(cond, self.norm_cond.weight, self.norm_cond.bias, self.norm_cond.eps)
-            kvc = ops.linear(cn, self.kv_cond.weight, self.kv_cond.bias)
+            if isinstance(cond, TextStates) and id(self) in cond.kv:
+                kvc = cond.kv[id(self)]          # projected up front with all the other layers (ops.text_kv)
+            else:
+                raw = cond.raw if isinstance(cond, TextStates) else cond
+                cn = ops.layer_norm(raw, self.norm_cond.weight, self.norm_cond.bias, self.norm_cond.eps)
+                kvc = ops.linear(cn, self.kv_cond.weight, self.kv_cond.bias)
         a = ops.attention(qkv.reshape(N, H * W, 3 * C), kvc, cond_mask if kvc is not None else None, self.num_heads)
         x = ops.conv(a.reshape(N, H, W, C), self.proj_out.weight, self.proj_out.bias, residual=x)
         if self.ffn is not None:
@@ -382,7 +411,18 @@ class UNet(nn.Module):
         if not self.masked_cross_attention:
             cond_mask = None
         cond_emb = ops.linear(y, self.cond_emb.weight, None)
-        return cond_emb, cond, cond_mask
+        return cond_emb, self.text_states(cond), cond_mask
+
+    def text_states(self, cond):
+        """every attention layer applies its own LayerNorm + Linear to the SAME text states (reference :263-264, 304):
+        in bf16 all of them are computed here, in one multi-norm launch and one grouped GEMM per width; sampling loops
+        that call forward_conditioning once (GraphedSampler) thereby hoist them out of the denoising loop"""
+        layers = [m for m in self.modules() if isinstance(m, SelfAttention) and m.cond_dim is not None and m.cond_dim > 0]
+        quads = [(m.norm_cond.weight, m.norm_cond.bias, m.kv_cond.weight, m.kv_cond.bias) for m in layers]
+        if not layers or not ops.text_kv_supported(cond, quads) or len({m.norm_cond.eps for m in layers}) != 1:
+            return TextStates(cond)
+        kv = ops.text_kv(cond, quads, layers[0].norm_cond.eps)
+        return TextStates(cond, {id(m): t for m, t in zip(layers, kv)})
 
     def forward_micro_conditioning(self, times, micros):
         temb = None

@@ -449,6 +449,36 @@ def test_deferred_grouped_wgrad_equals_immediate(L, C, mid_flush):
     assert torch.equal(out[0][2], out[1][2])
 
 
+@pytest.mark.parametrize("B,S,D,couts", [(4, 32, 128, [512, 512, 256, 512]), (64, 32, 2048, [1536] * 3 + [1024] * 2)])
+def test_text_kv_of_all_layers_at_once(B, S, D, couts):
+    """ops.text_kv (one multi-LayerNorm + grouped GEMMs for every attention layer's key / value projection of the text
+    states) == the layers one by one with torch (LayerNorm + Linear), outputs and every gradient; bf16"""
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(9)
+    dt = torch.bfloat16
+    cond = q(torch.randn(B, S, D, generator=g) * 1.5 + 0.2, dt).requires_grad_()
+    layers, gys = [], []
+    for c in couts:
+        layers.append([(1 + 0.3 * torch.randn(D, generator=g)).requires_grad_(), (0.2 * torch.randn(D, generator=g)).requires_grad_(),
+                       (torch.randn(c, D, generator=g) / D ** 0.5).requires_grad_(), (0.1 * torch.randn(c, generator=g)).requires_grad_()])
+        gys.append(q(torch.randn(B, S, c, generator=g), dt))
+    refs = [F.linear(q(F.layer_norm(cond, (D,), lw, lb, 1e-5), dt), q(w, dt), b) for lw, lb, w, b in layers]
+    sum((r * gy).sum() for r, gy in zip(refs, gys)).backward()
+    cd = cond.detach().to(dt).to(dev()).requires_grad_()
+    dl = [[t.detach().to(dev()).requires_grad_() for t in quad] for quad in layers]
+    assert ops.text_kv_supported(cd, dl)
+    outs = ops.text_kv(cd, dl)
+    sum((o.float() * gy.to(dev())).sum() for o, gy in zip(outs, gys)).backward()
+    tol = TOL[dt]
+    for o, r in zip(outs, refs):
+        assert relerr(o.float().cpu(), r) < tol
+    assert relerr(cd.grad.float().cpu(), cond.grad) < tol
+    for quad_d, quad in zip(dl, layers):
+        for a, b in zip(quad_d, quad):
+            assert relerr(a.grad, b.grad) < tol
+
+
 def test_fails_loudly_without_gpu_tensor():
     from mdm_hip import _lib, ops
 
