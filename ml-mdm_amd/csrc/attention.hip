@@ -39,8 +39,9 @@ struct AttnArgs {
   const void* dout;                                          // same strides as out
   const float* delta_self; const float* delta_cross;         // [B, H, L]
   void* dq;                                                  // strides as q
-  void* dk; void* dv; size_t dk_bs; int dk_rs;               // strides of the gradient of (k, v) being produced
-  int pass;                                                  // dkv kernel: 0 = self keys, 1 = cross keys
+  void* dk; void* dv; size_t dk_bs; int dk_rs;               // gradient of the self (k, v)
+  void* dkc; void* dvc; size_t dkc_bs; int dkc_rs;           // gradient of the cross (k_c, v_c); null if absent
+  float* delta_self_w; float* delta_cross_w;                 // written by the dQ kernel, read by the dK/dV kernel
   int B, H, L, S;
   float scale;                                               // 1/sqrt(d)
 };
@@ -55,6 +56,17 @@ template <> __device__ __forceinline__ void frag_from_global<float>(Frag<float>&
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   f.lo = valid ? *reinterpret_cast<const f32x4*>(p) : z;
   f.hi = valid ? *reinterpret_cast<const f32x4*>(p + 4) : z;
+}
+
+// the 8 elements of a fragment as fp32
+template <typename T> __device__ __forceinline__ void frag_to_f32(const Frag<T>& f, float (&o)[8]);
+template <> __device__ __forceinline__ void frag_to_f32<bf16>(const Frag<bf16>& f, float (&o)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (float)f.v[e];
+}
+template <> __device__ __forceinline__ void frag_to_f32<float>(const Frag<float>& f, float (&o)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = f.lo[e]; o[4 + e] = f.hi[e]; }
 }
 
 // two f32x4 score tiles -> one B fragment (8 consecutive reduction slots)
@@ -386,49 +398,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
 }
 
 // ---------------------------------------------------------------------------------------
-// backward pre-pass: delta_self = rowsum(dO * (O - O_cross)), delta_cross = rowsum(dO * O_cross)
-// ---------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ dout, const T* __restrict__ out,
-                                                         const T* __restrict__ oc, float* __restrict__ dself,
-                                                         float* __restrict__ dcross, int B, int H, int L, int d,
-                                                         size_t rows) {
-  // one thread per 16-byte chunk of a (b, i) row of C = H*d channels; partial dot products are combined per head
-  constexpr int EPV = Tr<T>::EPV;
-  __shared__ float pa[256], pc[256];
-  const int C = H * d, cpr = C / EPV, cph = d / EPV;
-  const int rpb = 256 / cpr > 0 ? 256 / cpr : 1;           // rows per block (cpr <= 256 checked on the host)
-  const int tid = threadIdx.x;
-  const int lr = tid / cpr, cc = tid - lr * cpr;
-  const size_t row = (size_t)blockIdx.x * rpb + lr;
-  float a = 0.f, c = 0.f;
-  if (lr < rpb && row < rows) {
-    const size_t off = row * C + (size_t)cc * EPV;
-    Chunk<T> g, o, x;
-    g.load(dout + off);
-    o.load(out + off);
-    if (oc) x.load(oc + off);
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-      const float cv = oc ? x.v[e] : 0.f;
-      a += g.v[e] * (o.v[e] - cv);
-      c += g.v[e] * cv;
-    }
-  }
-  pa[tid] = a; pc[tid] = c;
-  __syncthreads();
-  if (lr < rpb && row < rows && cc % cph == 0) {
-    float sa = 0.f, sc = 0.f;
-    for (int j = 0; j < cph; ++j) { sa += pa[tid + j]; sc += pc[tid + j]; }
-    const int h = cc / cph;
-    const size_t b = row / L, i = row - b * L;
-    const size_t o = (b * H + h) * L + i;
-    dself[o] = sa;
-    if (dcross) dcross[o] = sc;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
 // backward, dQ:   dS^T = P^T o (V dO^T - delta),  dQ^T = K^T dS^T  (both softmaxes accumulate)
 // ---------------------------------------------------------------------------------------
 template <typename T, int D, int QT>
@@ -470,6 +439,41 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     for (int dt = 0; dt < DT; ++dt) dq[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float c2 = p.scale * 1.4426950408889634f;
 
+  // delta_self = rowsum(dO * (O - O_cross)), delta_cross = rowsum(dO * O_cross) of this block's query rows, from the dO
+  // fragments already in registers (a lane holds 8 channels of row l16 per 32-channel step; the four quads of a row
+  // are summed with two shuffles).  Kept in registers for this kernel and stored for the dK / dV kernel that follows
+  // -- this used to be a separate streaming kernel per layer.
+  float del_self[QT], del_cross[QT];
+  {
+    const T* Op = reinterpret_cast<const T*>(p.out) + (size_t)b * p.o_bs + (size_t)h * D;
+    const T* Ocp = p.out_cross ? reinterpret_cast<const T*>(p.out_cross) + (size_t)b * p.o_bs + (size_t)h * D : nullptr;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int qi = q0 + qt * 16 + l16;
+      float a = 0.f, c = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < DS; ++ks) {
+        Frag<T> of, cf;
+        frag_from_global<T>(of, Op + (size_t)qi * p.o_rs + ks * 32 + quad * 8, qi < p.L);
+        frag_from_global<T>(cf, Ocp ? Ocp + (size_t)qi * p.o_rs + ks * 32 + quad * 8 : Op, Ocp != nullptr && qi < p.L);
+        float gv[8], ov[8], cv[8];
+        frag_to_f32<T>(gf[qt][ks], gv);
+        frag_to_f32<T>(of, ov);
+        frag_to_f32<T>(cf, cv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a += gv[e] * (ov[e] - cv[e]); c += gv[e] * cv[e]; }
+      }
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+      del_self[qt] = a; del_cross[qt] = c;
+      if (quad == 0 && qi < p.L) {
+        const size_t o = ((size_t)b * p.H + h) * p.L + qi;
+        p.delta_self_w[o] = a;
+        if (p.delta_cross_w) p.delta_cross_w[o] = c;
+      }
+    }
+  }
+
   const int npass = p.kc ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
     const T* Kp = reinterpret_cast<const T*>(pass ? p.kc : p.k) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
@@ -478,13 +482,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     const int nk = pass ? p.S : p.L;
     const float* mrow = (pass && p.mask) ? p.mask + (size_t)b * p.S : nullptr;
     const float* LSE = (pass ? p.lse_cross : p.lse_self) + ((size_t)b * p.H + h) * p.L;
-    const float* DEL = (pass ? p.delta_cross : p.delta_self) + ((size_t)b * p.H + h) * p.L;
     float lse[QT], del[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       const int qi = q0 + qt * 16 + l16;
       lse[qt] = (qi < p.L ? LSE[qi] : 1e30f) * 1.4426950408889634f;   // base-2 domain: p = 2^(s * c2 - lse2)
-      del[qt] = qi < p.L ? DEL[qi] : 0.f;
+      del[qt] = pass ? del_cross[qt] : del_self[qt];
     }
     // bf16: double-buffered K / V tiles with the next tile's global loads in flight during the MFMAs (see forward)
     constexpr bool PF = sizeof(T) == 2;
@@ -624,9 +627,14 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
   // 8 different L2s and fetch them from HBM 8 times (PMC: 1.38 GB per launch at L = 1024 against ~0.4 GB algorithmic).
   // The remap keeps them on one XCD.
   const int bx_ = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
-  const int by = bx_ / (int)gridDim.x, bx = bx_ - by * (int)gridDim.x;
+  const int by = bx_ / (int)gridDim.x;
+  int bx = bx_ - by * (int)gridDim.x;
   const int b = by / p.H, h = by - b * p.H;
-  const int pass = p.pass;
+  // one launch covers both key sets: the first ceil(L / (64 KT)) blocks of a (batch, head) own self keys, the rest
+  // the text (cross) keys
+  const int nself = (p.L + 64 * KT - 1) / (64 * KT);
+  const int pass = bx >= nself ? 1 : 0;
+  if (pass) bx -= nself;
   const int nk = pass ? p.S : p.L;
 
   const T* Kp = reinterpret_cast<const T*>(pass ? p.kc : p.k) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
@@ -772,8 +780,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
 #pragma unroll
   for (int kk = 0; kk < KT; ++kk) {
     if (!key_ok[kk]) continue;
-    T* DK = reinterpret_cast<T*>(p.dk) + (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key[kk] * p.dk_rs;
-    T* DV = reinterpret_cast<T*>(p.dv) + (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key[kk] * p.dk_rs;
+    T* DK = reinterpret_cast<T*>(pass ? p.dkc : p.dk) + (size_t)b * (pass ? p.dkc_bs : p.dk_bs) + (size_t)h * D + (size_t)key[kk] * (pass ? p.dkc_rs : p.dk_rs);
+    T* DV = reinterpret_cast<T*>(pass ? p.dvc : p.dv) + (size_t)b * (pass ? p.dkc_bs : p.dk_bs) + (size_t)h * D + (size_t)key[kk] * (pass ? p.dkc_rs : p.dk_rs);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -812,13 +820,11 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
   constexpr int DQ_QT = D >= 96 ? 1 : 2;
   ensure_dynamic_lds(attn_bwd_dq_kernel<T, D, DQ_QT>, smem_q);
   ensure_dynamic_lds(kkv, smem_kv);
+  a.delta_self_w = const_cast<float*>(a.delta_self); a.delta_cross_w = const_cast<float*>(a.delta_cross);
+  a.dkc = dkc; a.dvc = dvc; a.dkc_bs = dc_bs; a.dkc_rs = dc_rs;
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, DQ_QT>), dim3((a.L + 64 * DQ_QT - 1) / (64 * DQ_QT), a.B * a.H), dim3(256), smem_q, st, a);
-  a.pass = 0;
-  hipLaunchKernelGGL(kkv, dim3((a.L + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);
-  if (a.kc) {
-    a.pass = 1; a.dk = dkc; a.dv = dvc; a.dk_bs = dc_bs; a.dk_rs = dc_rs;
-    hipLaunchKernelGGL(kkv, dim3((a.S + 63) / 64, a.B * a.H), dim3(256), smem_kv, st, a);
-  }
+  const int nself = (a.L + 63) / 64, ncross = a.kc ? (a.S + 63) / 64 : 0;
+  hipLaunchKernelGGL(kkv, dim3(nself + ncross, a.B * a.H), dim3(256), smem_kv, st, a);
   MDM_LAUNCH_STATUS();
 }
 
@@ -868,22 +874,11 @@ extern "C" int mdm_attn_bwd(const void* qkv, const void* kvc, const float* mask,
   a.mask = mask; a.o_bs = (size_t)L * C; a.o_rs = C;
   a.lse_self = const_cast<float*>(lse_self); a.lse_cross = const_cast<float*>(lse_cross);
   a.dout = dout; a.delta_self = delta_self; a.delta_cross = delta_cross;
+  a.out = const_cast<void*>(out); a.out_cross = const_cast<void*>(out_cross);
   a.dq = dqkv; a.dk = (char*)dqkv + (size_t)C * es; a.dv = (char*)dqkv + (size_t)2 * C * es;
   a.dk_bs = a.q_bs; a.dk_rs = 3 * C;
   a.B = B; a.H = H; a.L = L; a.S = S; a.scale = 1.0f / sqrtf((float)d);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  {
-    const int epv = dtype == DT_F32 ? 4 : 8;
-    const int cpr = C / epv;
-    MDM_CHECK_ARG(cpr <= 256);
-    const int rpb = 256 / cpr;
-    const size_t rows = (size_t)B * L;
-    const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
-    if (dtype == DT_F32)
-      hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)(kvc ? out_cross : nullptr), delta_self, kvc ? delta_cross : nullptr, B, H, L, d, rows);
-    else
-      hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)dout, (const bf16*)out, (const bf16*)(kvc ? out_cross : nullptr), delta_self, kvc ? delta_cross : nullptr, B, H, L, d, rows);
-  }
   void* dkc = dkvc;
   void* dvc = kvc ? (char*)dkvc + (size_t)C * es : nullptr;
 #define MDM_ATTN_BWD(DD)                                                                                    \

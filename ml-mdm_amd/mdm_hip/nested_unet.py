@@ -104,7 +104,7 @@ class NestedUNet(UNet):
             x_t, x_feat = x_t
         bh, bl = x_t[0].size(0), x_t[1].size(0)
         x_t_low, x_hi = x_t[1:], x_t[0]
-        temb_act = ops.silu(temb[:bh] if bh != temb.shape[0] else temb)
+        temb_act = self.time_states(temb[:bh] if bh != temb.shape[0] else temb)
         cond_hi = conditioning[:bh] if (conditioning is not None and bh != conditioning.shape[0]) else conditioning
         mask_hi = cond_mask[:bh] if (cond_mask is not None and bh != cond_mask.shape[0]) else cond_mask
 

@@ -852,6 +852,86 @@ class TextKVFn(torch.autograd.Function):
         return (dcond, None) + tuple(grads)
 
 
+class SharedInputLinearsFn(torch.autograd.Function):
+    """y_l = x W_l^T + b_l for several linear layers that read the SAME input (every ResNet's ``time_layer`` applied to
+    silu(temb), reference unet.py:206, 227): one grouped GEMM per output width for the outputs, one for the input
+    gradients, one grouped weight-gradient launch -- instead of three tiny launches per layer.  bf16 only."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        _require_gpu(x)
+        x = _c(x)
+        R, D = x.shape
+        ws, bs = params[0::2], params[1::2]
+        L = len(ws)
+        lib = _lib.lib()
+        groups = {}
+        for l, w in enumerate(ws):
+            groups.setdefault(w.shape[0], []).append(l)
+        ys = [None] * L
+        for cout, idx in groups.items():
+            packs = [packed_weight(ws[l], bs[l], x.dtype) for l in idx]
+            for l in idx:
+                ys[l] = torch.empty((R, cout), dtype=x.dtype, device=x.device)
+            _lib.check(lib.mdm_linear_grouped(_ptr_array([x] * len(idx)), _ptr_array([pk[0] for pk in packs]),
+                                              _ptr_array([pk[2] for pk in packs]), _ptr_array([ys[l] for l in idx]), len(idx), R, D,
+                                              cout, _dt(x), _stream()), "mdm_linear_grouped")
+        ctx.save_for_backward(x, *params)
+        ctx.groups = groups
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, params = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        ws, bs = params[0::2], params[1::2]
+        L, groups = len(ws), ctx.groups
+        R, D = x.shape
+        lib = _lib.lib()
+        dys = [_c(d) if d is not None else torch.zeros((R, ws[l].shape[0]), dtype=x.dtype, device=x.device) for l, d in enumerate(dys)]
+        dxs = [torch.empty_like(x) for _ in range(L)]
+        grads = [None] * (2 * L)
+        for cout, idx in groups.items():
+            packs = [packed_weight(ws[l], bs[l], x.dtype) for l in idx]
+            _lib.check(lib.mdm_linear_grouped(_ptr_array([dys[l] for l in idx]), _ptr_array([pk[1] for pk in packs]), None,
+                                              _ptr_array([dxs[l] for l in idx]), len(idx), R, cout, D, _dt(x), _stream()),
+                       "mdm_linear_grouped")
+            slots = [(_slot(ws[l]), _slot(bs[l])) for l in idx]
+            sunk = all(a is not None and b is not None for a, b in slots)
+            if sunk:
+                dws, dbs = [a for a, _ in slots], [b for _, b in slots]
+            else:
+                dws = [torch.zeros(ws[l].shape, dtype=torch.float32, device=x.device) for l in idx]
+                dbs = [torch.zeros(bs[l].shape, dtype=torch.float32, device=x.device) for l in idx]
+            xs2, dy2 = [x] * len(idx), [dys[l] for l in idx]
+
+            def go(xs2=xs2, dy2=dy2, dws=dws, dbs=dbs, idx=idx, sunk=sunk):
+                wgrad_grouped(xs2, dy2, dws, dbs)
+                if sunk:
+                    for l in idx:
+                        _grad_sink.ready(ws[l])
+                        _grad_sink.ready(bs[l])
+
+            if sunk:
+                _off_critical_path([x] + dy2, go)
+            else:
+                go()
+                for k, l in enumerate(idx):
+                    grads[2 * l], grads[2 * l + 1] = dws[k], dbs[k]
+        dx = dxs[0] if L == 1 else torch.stack(dxs).sum(0)
+        return (dx,) + tuple(grads)
+
+
+def shared_input_linears_supported(x, layers):
+    return x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[-1] % 64 == 0 and 0 < len(layers) and \
+        all(w.shape[0] % 64 == 0 and b is not None for w, b in layers) and \
+        max(sum(1 for w2, _ in layers if w2.shape[0] == w.shape[0]) for w, _ in layers) <= 32
+
+
+def shared_input_linears(x, layers):
+    """layers: [(weight [Cout_l, D], bias [Cout_l])] -> tuple of x W_l^T + b_l"""
+    return SharedInputLinearsFn.apply(x, *[t for pair in layers for t in pair])
+
+
 def text_kv_supported(cond, layers):
     """the grouped path needs bf16 text states of a width the buffer-addressed GEMM takes"""
     return cond.is_cuda and cond.dtype == torch.bfloat16 and cond.shape[-1] % 64 == 0 and 0 < len(layers) <= 32 and \

@@ -127,7 +127,12 @@ class ResNet(nn.Module):
         g = self.config.num_groups_norm
         h, x = ops.group_norm(x, self.norm1.weight, self.norm1.bias, g, self.norm1.eps, silu=True, passthrough=True)
         h = ops.conv(h, self.conv1.weight, self.conv1.bias)
-        film = ops.linear(temb_act, self.time_layer.weight, self.time_layer.bias)
+        if isinstance(temb_act, TimeStates):
+            film = temb_act.film.get(id(self))
+            if film is None:
+                film = ops.linear(temb_act.act, self.time_layer.weight, self.time_layer.bias)
+        else:
+            film = ops.linear(temb_act, self.time_layer.weight, self.time_layer.bias)
         if film.shape[0] != h.shape[0]:
             raise NotImplementedError("time-embedding batch repeat (temporal mode) is not implemented")
         h = ops.group_norm(h, self.norm2.weight, self.norm2.bias, g, self.norm2.eps, film=film, silu=True)
@@ -135,6 +140,14 @@ class ResNet(nn.Module):
         if self.config.output_channels != self.config.num_channels:
             shortcut = ops.conv(x, self.conv3.weight, self.conv3.bias)
         return ops.conv(h, self.conv2.weight, self.conv2.bias, residual=shortcut)
+
+
+class TimeStates:
+    """silu(time embedding) [B, T] plus, when they were computed up front (bf16: grouped GEMMs over all ResNets of a
+    net, ops.shared_input_linears), every ResNet's FiLM projection ``time_layer(silu(temb))`` (reference :227)."""
+
+    def __init__(self, act, film=None):
+        self.act, self.film = act, film or {}
 
 
 class TextStates:
@@ -433,6 +446,17 @@ class UNet(nn.Module):
             temb = t if temb is None else ops.add(temb, t)
         return temb
 
+    def time_states(self, temb):
+        """silu(temb) and the FiLM projections of every ResNet of THIS net (not of a nested inner one), all at once"""
+        act = ops.silu(temb)
+        blocks = list(self.down_blocks) + (list(self.mid_blocks) if hasattr(self, "mid_blocks") else []) + list(self.up_blocks)
+        resnets = [r for b in blocks for r in b.resnets]
+        pairs = [(r.time_layer.weight, r.time_layer.bias) for r in resnets]
+        if not ops.shared_input_linears_supported(act, pairs):
+            return TimeStates(act)
+        films = ops.shared_input_linears(act, pairs)
+        return TimeStates(act, {id(r): f for r, f in zip(resnets, films)})
+
     def _time_embedding(self, times, cond_emb, micros):
         temb = self.create_temporal_embedding(times)
         if cond_emb is not None:
@@ -478,7 +502,7 @@ class UNet(nn.Module):
     def forward_denoising(self, x_t, times, cond_emb=None, conditioning=None, cond_mask=None, micros={}):
         """When ``config.nesting`` the input is ``(x_t, x_feat)`` with ``x_feat`` an NHWC feature map
         from the enclosing NestedUNet, and the result is ``(x_out, features)`` (reference :946-968)."""
-        temb_act = ops.silu(self._time_embedding(times, cond_emb, micros))
+        temb_act = self.time_states(self._time_embedding(times, cond_emb, micros))
         if self._config.nesting:
             x_t, x_feat = x_t
         x = self.forward_input_layer(x_t)

@@ -479,6 +479,31 @@ def test_text_kv_of_all_layers_at_once(B, S, D, couts):
             assert relerr(a.grad, b.grad) < tol
 
 
+@pytest.mark.parametrize("R,D,couts", [(64, 1024, [512] * 5 + [1024] * 5 + [1536] * 7), (3, 128, [64, 128, 64])])
+def test_linears_sharing_one_input(R, D, couts):
+    """ops.shared_input_linears (every ResNet's time_layer on silu(temb) as grouped GEMMs) == the layers one by one"""
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(10)
+    dt = torch.bfloat16
+    x = q(torch.randn(R, D, generator=g), dt).requires_grad_()
+    layers = [[(torch.randn(c, D, generator=g) / D ** 0.5).requires_grad_(), (0.1 * torch.randn(c, generator=g)).requires_grad_()] for c in couts]
+    gys = [q(torch.randn(R, c, generator=g), dt) for c in couts]
+    refs = [F.linear(x, q(w, dt), b) for w, b in layers]
+    sum((r * gy).sum() for r, gy in zip(refs, gys)).backward()
+    xd = x.detach().to(dt).to(dev()).requires_grad_()
+    dl = [[t.detach().to(dev()).requires_grad_() for t in pair] for pair in layers]
+    assert ops.shared_input_linears_supported(xd, dl)
+    outs = ops.shared_input_linears(xd, dl)
+    sum((o.float() * gy.to(dev())).sum() for o, gy in zip(outs, gys)).backward()
+    tol = TOL[dt]
+    for o, r in zip(outs, refs):
+        assert relerr(o.float().cpu(), r) < tol
+    assert relerr(xd.grad.float().cpu(), x.grad) < tol
+    for pd, pr in zip(dl, layers):
+        assert relerr(pd[0].grad, pr[0].grad) < tol and relerr(pd[1].grad, pr[1].grad) < tol
+
+
 def test_fails_loudly_without_gpu_tensor():
     from mdm_hip import _lib, ops
 
