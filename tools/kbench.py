@@ -59,9 +59,11 @@ def main():
         flops = 2.0 * B * Ho * Ho * cout * cin * ks * ks
         line = "%-22s" % name
         if what in ("fwd", "all"):
-            act = int(os.environ.get("KB_ACT", "0"))          # 1: GELU epilogue writing y and the pre-activation (FFN up)
+            act = int(os.environ.get("KB_ACT", "0"))          # 1: GELU epilogue writing y and the pre-activation (FFN up); 2: x gelu'(aux)
             ypre = torch.empty_like(y) if act == 1 else None
-            t = timeit(lambda: ops._conv_launch(x, wf, bp, None, None, y, ypre, B, H, H, cin, Ho, Ho, cout, ks, stride, 0, act, kbf))
+            aux = torch.randn_like(y) if act == 2 else None
+            res = torch.randn_like(y) if os.environ.get("KB_RES") == "1" else None   # + residual (proj_out, conv2, FFN down)
+            t = timeit(lambda: ops._conv_launch(x, wf, bp, res, aux, y, ypre, B, H, H, cin, Ho, Ho, cout, ks, stride, 0, act, kbf))
             line += "  fwd %7.3f ms %7.1f TF" % (t * 1e3, flops / t / 1e12)
         if what in ("dgrad", "all") and stride == 1:
             dx = torch.empty_like(x)
