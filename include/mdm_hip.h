@@ -161,14 +161,18 @@ int mdm_masked_mean_bwd(const void* dy, const float* mask, void* dx, int B, int 
  * replaces clip_grad_norm_ + AdamW.step + ModelEma.update + zero_grad (trainer.py:52-58,79-92;
  * clis/train_parallel.py:122-127; models/model_ema.py:25-34) -- thousands of per-tensor kernels in the
  * reference -- by two streaming passes.  All arenas hold the parameters in the same order.
- *   mdm_sumsq:          out[0] = sum g^2 (device scalar, no host sync); ws = fp32[1024]
+ *   mdm_sumsq:          out[0] = sum g^2 (device scalar, no host sync); ws = fp32[1024]; step_counter (device int or
+ *                       NULL) is incremented when the sum is finite -- the optimizer's step number then lives on the device
  *   mdm_adamw_ema_step: gs = gnorm_sq ? min(1, clip / (sqrt(*gnorm_sq) + 1e-6)) : 1; AdamW on (p, gs*g, m, v) with
- *                       bias correction for 1-based `step`; ema = ema*d + p*(1-d) if ema != NULL; g = 0 if zero_grad.
+ *                       bias correction for 1-based `step` (or *step_dev when non-NULL); ema = ema*d + p*(1-d) if
+ *                       ema != NULL; g = 0 if zero_grad.  A non-finite *gnorm_sq (a NaN / inf loss or gradient) skips the
+ *                       update and only clears g: what trainer.py:38-41 does by returning before backward, without the
+ *                       host having to look at the loss in the middle of the step.
  */
-int mdm_sumsq(const float* g, float* out, float* ws, size_t n, void* stream);
+int mdm_sumsq(const float* g, float* out, float* ws, size_t n, int* step_counter, void* stream);
 int mdm_adamw_ema_step(float* p, float* g, float* m, float* v, float* ema, const float* gnorm_sq, size_t n, float lr,
-                       float beta1, float beta2, float eps, float weight_decay, int step, float clip, float ema_decay,
-                       int zero_grad, void* stream);
+                       float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
+                       float clip, float ema_decay, int zero_grad, void* stream);
 
 /* ---- per-pixel arithmetic around the denoiser (NCHW fp32 images, as the reference keeps them) ---------------
  * All [B, chw] images need chw % 4 == 0.  gamma / gamma_last are per-sample device vectors [B].

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int nparts,
                                                           const float* __restrict__ g, size_t n, size_t tail_from,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, int* __restrict__ step_counter) {
   __shared__ float sh[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
@@ -39,12 +39,18 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = sh[0] + sh[1] + sh[2] + sh[3];
+  if (threadIdx.x == 0) {
+    const float q = sh[0] + sh[1] + sh[2] + sh[3];
+    out[0] = q;
+    // the optimizer's step number lives on the device and advances only when the update will be applied
+    if (step_counter && q == q && q <= 3.0e38f) step_counter[0] += 1;
+  }
 }
 
 struct AdamArgs {
   float* p; float* g; float* m; float* v; float* ema;
   const float* gnorm_sq;   // device scalar (sum of squares of g) or null = no clipping
+  const int* step_dev;     // device step number (1-based) or null = bc1 / bc2 computed on the host
   size_t n;
   float lr, beta1, beta2, eps, wd, bc1, bc2, clip, ema_decay;
   int zero_grad;
@@ -63,6 +69,11 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 }
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
+  if (a.step_dev) {
+    const float st = (float)a.step_dev[0];
+    a.bc1 = 1.f - powf(a.beta1, st);
+    a.bc2 = 1.f - powf(a.beta2, st);
+  }
   float gs = 1.f;
   bool poisoned = false;
   if (a.gnorm_sq) {
@@ -112,8 +123,8 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
 
 using namespace mdm;
 
-// out[0] = sum_i g[i]^2.  ws: fp32 [1024].
-extern "C" int mdm_sumsq(const float* g, float* out, float* ws, size_t n, void* stream) {
+// out[0] = sum_i g[i]^2.  ws: fp32 [1024].  step_counter (device int, may be NULL) += 1 when the sum is finite.
+extern "C" int mdm_sumsq(const float* g, float* out, float* ws, size_t n, int* step_counter, void* stream) {
   MDM_CHECK_ARG(g && out && ws);
   MDM_CHECK_ARG(((size_t)g & 15) == 0);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -121,25 +132,27 @@ extern "C" int mdm_sumsq(const float* g, float* out, float* ws, size_t n, void* 
   int nb = (int)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, g, ws, n4);
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, ws, nb, g, n, n4 * 4, out);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, ws, nb, g, n, n4 * 4, out, step_counter);
   MDM_LAUNCH_STATUS();
 }
 
 // One fused optimizer step over flat fp32 arenas of n elements (all 16-byte aligned):
 //   gs = gnorm_sq ? min(1, clip / (sqrt(*gnorm_sq) + 1e-6)) : 1          (gradient-norm clipping)
-//   AdamW(lr, beta1, beta2, eps, weight_decay) on (p, g*gs, m, v) for step number `step` (1-based, bias correction)
+//   AdamW(lr, beta1, beta2, eps, weight_decay) on (p, g*gs, m, v) for step number `step` (1-based, bias correction), or
+//   for the device-resident step number *step_dev when that is given (mdm_sumsq advances it only for finite norms)
 //   ema = ema * ema_decay + p * (1 - ema_decay)   (skipped when ema == NULL)
 //   g = 0 when zero_grad != 0
 extern "C" int mdm_adamw_ema_step(float* p, float* g, float* m, float* v, float* ema, const float* gnorm_sq, size_t n,
                                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                                  float clip, float ema_decay, int zero_grad, void* stream) {
-  MDM_CHECK_ARG(p && g && m && v && step >= 1);
+                                  const int* step_dev, float clip, float ema_decay, int zero_grad, void* stream) {
+  MDM_CHECK_ARG(p && g && m && v && (step >= 1 || step_dev));
   MDM_CHECK_ARG((((size_t)p | (size_t)g | (size_t)m | (size_t)v | (size_t)ema) & 15) == 0);
   AdamArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.ema = ema; a.gnorm_sq = gnorm_sq; a.n = n;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
-  a.bc1 = 1.f - powf(beta1, (float)step);
-  a.bc2 = 1.f - powf(beta2, (float)step);
+  a.step_dev = step_dev;
+  a.bc1 = 1.f - powf(beta1, (float)(step >= 1 ? step : 1));
+  a.bc2 = 1.f - powf(beta2, (float)(step >= 1 ? step : 1));
   a.clip = clip; a.ema_decay = ema_decay; a.zero_grad = zero_grad;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t n4 = n / 4;

@@ -1406,22 +1406,24 @@ def input_stage(u8_nhwc):
 # --------------------------------------------------------------------------------------
 # optimizer tail
 # --------------------------------------------------------------------------------------
-def sumsq(flat_f32, out=None):
-    """device scalar sum(g^2) of a flat fp32 arena (no host sync)"""
+def sumsq(flat_f32, out=None, step_counter=None):
+    """device scalar sum(g^2) of a flat fp32 arena (no host sync); ``step_counter`` (device int32[1]) += 1 when finite"""
     _require_gpu(flat_f32)
     out = torch.empty(1, dtype=torch.float32, device=flat_f32.device) if out is None else out
     ws = torch.empty(1024, dtype=torch.float32, device=flat_f32.device)
-    _lib.check(_lib.lib().mdm_sumsq(_p(flat_f32), _p(out), _p(ws), flat_f32.numel(), _stream()), "mdm_sumsq")
+    _lib.check(_lib.lib().mdm_sumsq(_p(flat_f32), _p(out), _p(ws), flat_f32.numel(), _p(step_counter), _stream()), "mdm_sumsq")
     return out
 
 
-def adamw_ema_step(p, g, m, v, ema, gnorm_sq, lr, beta1, beta2, eps, weight_decay, step, clip, ema_decay, zero_grad=True):
-    """one fused clip + AdamW + EMA (+ zero-grad) pass over flat fp32 arenas; invalidates the packed-weight cache"""
+def adamw_ema_step(p, g, m, v, ema, gnorm_sq, lr, beta1, beta2, eps, weight_decay, step, clip, ema_decay, zero_grad=True,
+                   step_dev=None):
+    """one fused clip + AdamW + EMA (+ zero-grad) pass over flat fp32 arenas; invalidates the packed-weight cache.
+    ``step_dev`` (device int32[1]) overrides ``step`` for the bias correction."""
     _require_gpu(p)
     nbytes = 4.0 * p.numel() * ((4 if ema is None else 5) + (3 if ema is None else 4) + (1 if zero_grad else 0))
     _prof_wrap("adamw_ema_step", nbytes, lambda: _lib.check(
         _lib.lib().mdm_adamw_ema_step(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(gnorm_sq), p.numel(), float(lr), float(beta1),
-                                      float(beta2), float(eps), float(weight_decay), int(step), float(clip), float(ema_decay),
+                                      float(beta2), float(eps), float(weight_decay), int(step), _p(step_dev), float(clip), float(ema_decay),
                                       1 if zero_grad else 0, _stream()),
         "mdm_adamw_ema_step",
     ), kind="hbm")

@@ -51,6 +51,7 @@ class TrainStep:
             self.v = torch.zeros_like(flat)
             self.flat_ema = flat.clone() if use_ema else None
             self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            self.step_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)   # optimizer step number, on the device
             self.reducer.rebind()
             ops.set_grad_sink(self.reducer)
             ops.enable_async_wgrad(async_wgrad)
@@ -79,6 +80,23 @@ class TrainStep:
         with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=self.bf16):
             losses, times, x_t, means, targets, weights = self.pipeline.get_loss(sample, **loss_kw)
             loss = losses.mean() if weights is None else (losses * weights).sum() / weights.sum()
+        if self.fused:
+            # No host look at the loss in the middle of the step: a NaN / inf loss gives a non-finite gradient norm, and
+            # the fused optimizer then skips the update, clears the gradients and does not advance its (device-side)
+            # step number -- the outcome of the reference's early return (trainer.py:37-41) on every rank alike, without
+            # stalling the launch queue between forward and backward.
+            loss.backward()
+            ops.flush_wgrad_queue()
+            ops.join_side_stream()
+            self.reducer.finish()
+            ops.sumsq(self.reducer.flat, out=self.gnorm_sq, step_counter=self.step_dev)
+            ops.adamw_ema_step(self.flat_p, self.reducer.flat, self.m, self.v, self.flat_ema, self.gnorm_sq, self.lr,
+                               self.betas[0], self.betas[1], self.eps, self.weight_decay, 0, self.clip_norm,
+                               self.ema_decay, zero_grad=True, step_dev=self.step_dev)
+            ops.repack_all(torch.bfloat16 if self.bf16 else torch.float32)   # one launch instead of one per weight
+            loss_val = loss.item()   # the step's only host synchronisation (the reference's is at trainer.py:37)
+            self.steps += 1 if math.isfinite(loss_val) else 0
+            return loss_val
         loss_val = loss.item()  # the reference syncs here every step (trainer.py:37)
         bad = not math.isfinite(loss_val)
         if self.reducer.world > 1:
@@ -95,13 +113,6 @@ class TrainStep:
         ops.join_side_stream()
         self.reducer.finish()
         self.steps += 1
-        if self.fused:
-            ops.sumsq(self.reducer.flat, out=self.gnorm_sq)
-            ops.adamw_ema_step(self.flat_p, self.reducer.flat, self.m, self.v, self.flat_ema, self.gnorm_sq, self.lr,
-                               self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps, self.clip_norm,
-                               self.ema_decay, zero_grad=True)
-            ops.repack_all(torch.bfloat16 if self.bf16 else torch.float32)   # one launch instead of one per weight
-            return loss_val
         gnorm = torch.linalg.vector_norm(self.reducer.flat)
         scale = torch.clamp(self.clip_norm / (gnorm + 1e-6), max=1.0)
         self.reducer.flat.mul_(scale)  # == clip_grad_norm_ over all parameters (one pass over the arena)

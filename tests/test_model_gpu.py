@@ -174,6 +174,33 @@ def test_fused_train_step_matches_torch_optimizer():
         assert O.rel_l2(p1[k], p0[k]) < 5e-3, k
 
 
+def test_non_finite_step_is_skipped_on_the_device():
+    """a NaN loss (here: a NaN in the images) must leave parameters, moments, EMA and the optimizer's step number untouched
+    and clear the gradients -- decided on the device from the gradient norm, no host look at the loss mid-step
+    (reference trainer.py:37-41 returns before backward)"""
+    from mdm_hip import ops
+    from mdm_hip.trainer import TrainStep
+
+    ops.set_grad_sink(None)
+    model, _, _ = PC.build_module("mini_unet")
+    pipe = _pipeline("mini_unet", model).to(torch.device("cuda:0"))
+    step = TrainStep(pipe, bf16=False, lr=1e-2, fused=True)
+    inp = PC.inputs("mini_unet")
+    g = torch.Generator().manual_seed(3)
+    smp = {"lm_outputs": inp["cond"].cuda(), "lm_mask": inp["mask"].cuda(), "images": (torch.rand(2, 3, 16, 16, generator=g) * 2 - 1).cuda()}
+    step(smp)
+    p1, m1, e1 = step.flat_p.clone(), step.m.clone(), step.flat_ema.clone()
+    bad = dict(smp, images=smp["images"].clone())
+    bad["images"][0, 0, 0, 0] = float("nan")
+    lv = step(bad)
+    assert lv != lv
+    assert torch.equal(step.flat_p, p1) and torch.equal(step.m, m1) and torch.equal(step.flat_ema, e1)
+    assert float(step.reducer.flat.abs().max()) == 0.0 and int(step.step_dev) == 1 and step.steps == 1
+    step(smp)
+    ops.set_grad_sink(None)
+    assert int(step.step_dev) == 2 and not torch.equal(step.flat_p, p1) and bool(torch.isfinite(step.flat_p).all())
+
+
 def test_weights_are_repacked_after_an_optimizer_step():
     """the packed kernel-layout weights must follow parameter updates that do not bump Tensor._version"""
     from mdm_hip import ops
