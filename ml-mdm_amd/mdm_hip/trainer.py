@@ -81,10 +81,12 @@ class TrainStep:
             losses, times, x_t, means, targets, weights = self.pipeline.get_loss(sample, **loss_kw)
             loss = losses.mean() if weights is None else (losses * weights).sum() / weights.sum()
         if self.fused:
-            # No host look at the loss in the middle of the step: a NaN / inf loss gives a non-finite gradient norm, and
-            # the fused optimizer then skips the update, clears the gradients and does not advance its (device-side)
-            # step number -- the outcome of the reference's early return (trainer.py:37-41) on every rank alike, without
-            # stalling the launch queue between forward and backward.
+            # The loss is read where the reference reads it (trainer.py:37) -- by then the host has queued the whole
+            # forward, and it queues the next step's forward while this step's backward runs -- but nothing branches on
+            # it: a NaN / inf loss gives a non-finite gradient norm, and the fused optimizer then skips the update,
+            # clears the gradients and does not advance its (device-side) step number.  Same outcome as the reference's
+            # early return (trainer.py:38-41), identical on every rank without a collective.
+            loss_val = loss.item()
             loss.backward()
             ops.flush_wgrad_queue()
             ops.join_side_stream()
@@ -94,7 +96,6 @@ class TrainStep:
                                self.betas[0], self.betas[1], self.eps, self.weight_decay, 0, self.clip_norm,
                                self.ema_decay, zero_grad=True, step_dev=self.step_dev)
             ops.repack_all(torch.bfloat16 if self.bf16 else torch.float32)   # one launch instead of one per weight
-            loss_val = loss.item()   # the step's only host synchronisation (the reference's is at trainer.py:37)
             self.steps += 1 if math.isfinite(loss_val) else 0
             return loss_val
         loss_val = loss.item()  # the reference syncs here every step (trainer.py:37)
