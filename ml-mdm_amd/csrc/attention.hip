@@ -126,18 +126,33 @@ __device__ __forceinline__ void load_tr_tile(char* dst, const T* src, int rs, in
 // The same natural tile in two steps, so the global loads of the NEXT tile can be in flight while the MFMAs of the
 // current one run: fetch (HBM -> registers) ... compute ... commit (registers -> LDS).
 template <typename T, int D> struct NatRegs { uint4 v[(64 * AttnGeom<T, D>::CPR + 255) / 256]; };
-template <typename T, int D>
-__device__ __forceinline__ void fetch_nat(NatRegs<T, D>& r, const T* src, int rs, int row0, int nrows, int tid) {
-  using G = AttnGeom<T, D>;
-  constexpr int NV = (64 * G::CPR + 255) / 256;
+// The global side goes through a buffer descriptor over rows [0, nrows) of the head view: per-lane byte offsets are
+// computed once, a tile is one 32-bit add per load, and rows past the end read as zero by the range check (no 64-bit
+// address arithmetic or per-element selects inside the key loop).
+template <typename T, int D> struct NatSrc {
+  static constexpr int NV = (64 * AttnGeom<T, D>::CPR + 255) / 256;
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned vo[NV];
+  unsigned row_bytes;
+  __device__ __forceinline__ NatSrc(const T* src, int rs, int nrows, int tid) {
+    using G = AttnGeom<T, D>;
+    row_bytes = (unsigned)rs * (unsigned)sizeof(T);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(src), 0, (unsigned)nrows * row_bytes, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = tid + 256 * i;
-    const int row = c / G::CPR, cc = c - row * G::CPR;
-    const bool ok = c < 64 * G::CPR && row0 + row < nrows;
-    uint4 val = *reinterpret_cast<const uint4*>(src + (ok ? (size_t)(row0 + row) * rs + cc * G::EPV : (size_t)0));
-    val.x = ok ? val.x : 0u; val.y = ok ? val.y : 0u; val.z = ok ? val.z : 0u; val.w = ok ? val.w : 0u;
-    r.v[i] = val;
+    for (int i = 0; i < NV; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c / G::CPR, cc = c - row * G::CPR;
+      vo[i] = c < 64 * G::CPR ? (unsigned)row * row_bytes + (unsigned)(cc * 16) : 0x7F000000u;
+    }
+  }
+};
+template <typename T, int D>
+__device__ __forceinline__ void fetch_nat(NatRegs<T, D>& r, const NatSrc<T, D>& s, int row0) {
+  const unsigned base = (unsigned)row0 * s.row_bytes;
+#pragma unroll
+  for (int i = 0; i < NatSrc<T, D>::NV; ++i) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, s.vo[i] + base, 0, 0);
+    r.v[i] = uint4{(unsigned)v[0], (unsigned)v[1], (unsigned)v[2], (unsigned)v[3]};
   }
 }
 template <typename T, int D>
@@ -256,11 +271,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     // fp32: K natural + V transposed, staged synchronously (ds_read_tr is a 16-bit instruction).
     constexpr bool PF = sizeof(T) == 2;
     NatRegs<T, D> kr, vr;
+    const NatSrc<T, D> ksrc(Kp, rs, nk, tid), vsrc(Vp, rs, nk, tid);
     int it = 0;
     if constexpr (PF) {
       __syncthreads();   // the previous pass may still be reading buffer 0
-      fetch_nat<T, D>(kr, Kp, rs, 0, nk, tid);
-      fetch_nat<T, D>(vr, Vp, rs, 0, nk, tid);
+      fetch_nat<T, D>(kr, ksrc, 0);
+      fetch_nat<T, D>(vr, vsrc, 0);
       commit_nat<T, D>(smem, kr, tid);
       commit_nat<T, D>(smem + G::NAT_BYTES, vr, tid);
     }
@@ -270,8 +286,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         Ks = smem + (it & 1) * (2 * G::NAT_BYTES);
         Vs = Ks + G::NAT_BYTES;
         if (k0 + 64 < nk) {
-          fetch_nat<T, D>(kr, Kp, rs, k0 + 64, nk, tid);
-          fetch_nat<T, D>(vr, Vp, rs, k0 + 64, nk, tid);
+          fetch_nat<T, D>(kr, ksrc, k0 + 64);
+          fetch_nat<T, D>(vr, vsrc, k0 + 64);
         }
       } else {
         load_nat_tile<T, D>(Ks, Kp, rs, k0, nk, tid);
@@ -492,11 +508,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     // bf16: double-buffered K / V tiles with the next tile's global loads in flight during the MFMAs (see forward)
     constexpr bool PF = sizeof(T) == 2;
     NatRegs<T, D> kr, vr;
+    const NatSrc<T, D> ksrc(Kp, rs, nk, tid), vsrc(Vp, rs, nk, tid);
     int it = 0;
     if constexpr (PF) {
       __syncthreads();
-      fetch_nat<T, D>(kr, Kp, rs, 0, nk, tid);
-      fetch_nat<T, D>(vr, Vp, rs, 0, nk, tid);
+      fetch_nat<T, D>(kr, ksrc, 0);
+      fetch_nat<T, D>(vr, vsrc, 0);
       commit_nat<T, D>(smem, kr, tid);
       commit_nat<T, D>(smem + G::NAT_BYTES, vr, tid);
     }
@@ -506,8 +523,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
         Ks = smem + (it & 1) * (2 * G::NAT_BYTES);
         Vs = Ks + G::NAT_BYTES;
         if (k0 + 64 < nk) {
-          fetch_nat<T, D>(kr, Kp, rs, k0 + 64, nk, tid);
-          fetch_nat<T, D>(vr, Vp, rs, k0 + 64, nk, tid);
+          fetch_nat<T, D>(kr, ksrc, k0 + 64);
+          fetch_nat<T, D>(vr, vsrc, k0 + 64);
         }
       } else {
         load_nat_tile<T, D>(Ks, Kp, rs, k0, nk, tid);
@@ -672,11 +689,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
   constexpr bool PF = sizeof(T) == 2;
   constexpr int BUF = 2 * G::NAT_BYTES + 512;   // one stage: Q, dO, lse[64], delta[64]
   NatRegs<T, D> qr, gr;
+  const NatSrc<T, D> qsrc(Q, p.q_rs, p.L, tid), gsrc(DO, p.o_rs, p.L, tid);
   float lse_r = 0.f, del_r = 0.f;
   int it = 0;
   if constexpr (PF) {
-    fetch_nat<T, D>(qr, Q, p.q_rs, 0, p.L, tid);
-    fetch_nat<T, D>(gr, DO, p.o_rs, 0, p.L, tid);
+    fetch_nat<T, D>(qr, qsrc, 0);
+    fetch_nat<T, D>(gr, gsrc, 0);
     commit_nat<T, D>(smem, qr, tid);
     commit_nat<T, D>(smem + G::NAT_BYTES, gr, tid);
     if (tid < 64) {
@@ -693,8 +711,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
       lse_s = reinterpret_cast<float*>(Qs + 2 * G::NAT_BYTES);
       del_s = lse_s + 64;
       if (q0 + 64 < p.L) {
-        fetch_nat<T, D>(qr, Q, p.q_rs, q0 + 64, p.L, tid);
-        fetch_nat<T, D>(gr, DO, p.o_rs, q0 + 64, p.L, tid);
+        fetch_nat<T, D>(qr, qsrc, q0 + 64);
+        fetch_nat<T, D>(gr, gsrc, q0 + 64);
         if (tid < 64) {
           const int qi = q0 + 64 + tid;
           lse_r = (qi < p.L ? LSE[qi] : 1e30f) * 1.4426950408889634f;

@@ -201,3 +201,26 @@ def test_gpu_get_loss_equals_cpu_formulation():
         for a, b in zip(res[1][:3], res[0][:3]):
             assert relerr(a, b) < 1e-5
         assert relerr(res[1][3], res[0][3]) < 2e-4   # one scalar = a sum over every pixel: summation order
+
+
+def test_input_stager_matches_reference_loop():
+    """N4: pinned double-buffered load_batch + the uint8 -> normalised image kernel == clis/train_parallel.py:35-50,194-195"""
+    import numpy as np
+    from mdm_hip.input_stage import load_batch
+    rng = np.random.default_rng(0)
+    batches = []
+    for i in range(4):   # more batches than slots: the pinned buffers are reused
+        batches.append(dict(image=rng.integers(0, 256, (3, 16, 16, 3), dtype=np.uint8),
+                            text_embedding=rng.standard_normal((3, 5, 8)).astype(np.float32),
+                            state=np.array([[32.0, 32.0], [64.0, 16.0], [16.0, 16.0]], dtype=np.float32),
+                            watermark_score=np.array([[ord(c) for c in "0.25"] + [0, 0]] * 3, dtype=np.uint8),
+                            tokens=np.arange(6, dtype=np.int64).reshape(3, 2)))
+    staged = [load_batch(dict(b), "cuda") for b in batches]   # all submitted before any is consumed
+    for b, s in zip(batches, staged):
+        want = torch.permute((torch.from_numpy(b["image"]).float() - 127.0) / 128.0, (0, 3, 1, 2))
+        assert torch.equal(s["images"].cpu(), want)
+        assert torch.equal(s["image"].cpu(), torch.from_numpy(b["image"]).float())
+        assert torch.equal(s["text_embedding"].cpu(), torch.from_numpy(b["text_embedding"]))
+        assert torch.allclose(s["scale"].cpu(), 16.0 / torch.from_numpy(b["state"][:, 0]))
+        assert torch.allclose(s["watermark_score"].cpu(), torch.full((3,), 0.25))
+        assert isinstance(s["tokens"], np.ndarray)
