@@ -192,6 +192,32 @@ struct FragT {
     f.v = *reinterpret_cast<bf16x8*>(&v);
   }
 };
+// The per-lane byte offsets of FragT::bf inside a natural tile, computed once per kernel: the read of channel tile c16,
+// row half hh is then `tile + lo[c16] + hh * 4096` (rows + 32 keep their swizzle), an immediate when `tile` is a
+// compile-time LDS offset.
+template <int D> struct TrOff {
+  unsigned lo[D / 16], hi[D / 16];
+  __device__ __forceinline__ TrOff(int quad, int l16) {
+#pragma unroll
+    for (int c16 = 0; c16 < D / 16; ++c16) {
+      const int d = c16 * 16 + (l16 & 3) * 4;
+      const int r = quad * 8 + (l16 >> 2);
+      const unsigned base = (unsigned)((d >> 6) * (64 * 128) + (((d >> 2) & 1) << 3));
+      lo[c16] = base + (unsigned)lds_chunk_off(r, (d & 63) >> 3);
+      hi[c16] = base + (unsigned)lds_chunk_off(r + 4, (d & 63) >> 3);
+    }
+  }
+  __device__ __forceinline__ void read(Frag<bf16>& f, const char* nat, int c16, int hh) const {
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(nat + lo[c16] + hh * 4096));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(nat + hi[c16] + hh * 4096));
+    s16x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    f.v = *reinterpret_cast<bf16x8*>(&v);
+  }
+};
+template <int N> struct IntC { static constexpr int value = N; };
+
 template <typename T, int D>
 __device__ __forceinline__ void load_frag_T(Frag<T>& f, const char* nat, const char* tr, int c16, int hh, int quad, int l16) {
   if constexpr (sizeof(T) == 2) {
@@ -221,6 +247,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int quad = lane >> 4, l16 = lane & 15;
+  const TrOff<D> troff(quad, l16);
   // XCD-aware block order: the hardware deals consecutive workgroups round-robin over the 8 XCDs, so with the natural
   // (tile, head) order the tiles of one (batch, head) -- which all stream the same K / V (or Q / dO) rows -- land on
   // 8 different L2s and fetch them from HBM 8 times (PMC: 1.38 GB per launch at L = 1024 against ~0.4 GB algorithmic).
@@ -272,7 +299,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     constexpr bool PF = sizeof(T) == 2;
     NatRegs<T, D> kr, vr;
     const NatSrc<T, D> ksrc(Kp, rs, nk, tid), vsrc(Vp, rs, nk, tid);
-    int it = 0;
     if constexpr (PF) {
       __syncthreads();   // the previous pass may still be reading buffer 0
       fetch_nat<T, D>(kr, ksrc, 0);
@@ -280,10 +306,13 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
       commit_nat<T, D>(smem, kr, tid);
       commit_nat<T, D>(smem + G::NAT_BYTES, vr, tid);
     }
-    for (int k0 = 0; k0 < nk; k0 += 64) {
+    // one 64-key tile out of LDS stage CUR (a compile-time constant, so that every fragment address of the tile is
+    // `per-lane offset + immediate`: the loop below alternates two instantiations instead of computing addresses)
+    auto tile = [&](auto cur_c, const int k0) {
+      constexpr int CUR = decltype(cur_c)::value;
       __syncthreads();
       if constexpr (PF) {
-        Ks = smem + (it & 1) * (2 * G::NAT_BYTES);
+        Ks = smem + CUR * (2 * G::NAT_BYTES);
         Vs = Ks + G::NAT_BYTES;
         if (k0 + 64 < nk) {
           fetch_nat<T, D>(kr, ksrc, k0 + 64);
@@ -358,19 +387,22 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           Frag<T> vf;
-          if constexpr (PF) load_frag_T<T, D>(vf, Vs, nullptr, dt, hh, quad, l16);
+          if constexpr (PF) troff.read(vf, Vs, dt, hh);
           else load_frag<T>(vf, Vs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) mma16(o[qt][dt], vf, pf[qt][hh]);
         }
       if constexpr (PF) {
         if (k0 + 64 < nk) {
-          char* nb = smem + ((it + 1) & 1) * (2 * G::NAT_BYTES);
+          char* nb = smem + (1 - CUR) * (2 * G::NAT_BYTES);
           commit_nat<T, D>(nb, kr, tid);
           commit_nat<T, D>(nb + G::NAT_BYTES, vr, tid);
         }
-        ++it;
       }
+    };
+    for (int k0 = 0; k0 < nk; k0 += 128) {
+      tile(IntC<0>{}, k0);
+      if (k0 + 64 < nk) tile(IntC<1>{}, k0 + 64);
     }
 
     // finalise this softmax
@@ -427,6 +459,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int quad = lane >> 4, l16 = lane & 15;
+  const TrOff<D> troff(quad, l16);
   // XCD-aware block order: the hardware deals consecutive workgroups round-robin over the 8 XCDs, so with the natural
   // (tile, head) order the tiles of one (batch, head) -- which all stream the same K / V (or Q / dO) rows -- land on
   // 8 different L2s and fetch them from HBM 8 times (PMC: 1.38 GB per launch at L = 1024 against ~0.4 GB algorithmic).
@@ -509,7 +542,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     constexpr bool PF = sizeof(T) == 2;
     NatRegs<T, D> kr, vr;
     const NatSrc<T, D> ksrc(Kp, rs, nk, tid), vsrc(Vp, rs, nk, tid);
-    int it = 0;
     if constexpr (PF) {
       __syncthreads();
       fetch_nat<T, D>(kr, ksrc, 0);
@@ -517,10 +549,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
       commit_nat<T, D>(smem, kr, tid);
       commit_nat<T, D>(smem + G::NAT_BYTES, vr, tid);
     }
-    for (int k0 = 0; k0 < nk; k0 += 64) {
+    // one 64-key tile out of LDS stage CUR (compile-time: fragment addresses = per-lane offset + immediate; see forward)
+    auto tile = [&](auto cur_c, const int k0) {
+      constexpr int CUR = decltype(cur_c)::value;
       __syncthreads();
       if constexpr (PF) {
-        Ks = smem + (it & 1) * (2 * G::NAT_BYTES);
+        Ks = smem + CUR * (2 * G::NAT_BYTES);
         Vs = Ks + G::NAT_BYTES;
         if (k0 + 64 < nk) {
           fetch_nat<T, D>(kr, ksrc, k0 + 64);
@@ -589,18 +623,22 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           Frag<T> ktf;
-          load_frag_T<T, D>(ktf, Ks, KTs, dt, hh, quad, l16);
+          if constexpr (PF) troff.read(ktf, Ks, dt, hh);
+          else load_frag_T<T, D>(ktf, Ks, KTs, dt, hh, quad, l16);
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) mma16(dq[qt][dt], ktf, dsf[qt][hh]);
         }
       if constexpr (PF) {
         if (k0 + 64 < nk) {
-          char* nb = smem + ((it + 1) & 1) * (2 * G::NAT_BYTES);
+          char* nb = smem + (1 - CUR) * (2 * G::NAT_BYTES);
           commit_nat<T, D>(nb, kr, tid);
           commit_nat<T, D>(nb + G::NAT_BYTES, vr, tid);
         }
-        ++it;
       }
+    };
+    for (int k0 = 0; k0 < nk; k0 += 128) {
+      tile(IntC<0>{}, k0);
+      if (k0 + 64 < nk) tile(IntC<1>{}, k0 + 64);
     }
   }
   T* DQ = reinterpret_cast<T*>(p.dq) + (size_t)b * p.q_bs + (size_t)h * D;
@@ -639,6 +677,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int quad = lane >> 4, l16 = lane & 15;
+  const TrOff<D> troff(quad, l16);
   // XCD-aware block order: the hardware deals consecutive workgroups round-robin over the 8 XCDs, so with the natural
   // (tile, head) order the tiles of one (batch, head) -- which all stream the same K / V (or Q / dO) rows -- land on
   // 8 different L2s and fetch them from HBM 8 times (PMC: 1.38 GB per launch at L = 1024 against ~0.4 GB algorithmic).
@@ -659,11 +698,13 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
   const int rs = pass ? p.c_rs : p.k_rs;
   int key[KT];
   bool key_ok[KT], key_live[KT];
+  bool tile_live[KT];   // wave-uniform: this 16-key tile holds at least one real key (a dead tile skips its MFMAs)
   Frag<T> kf[KT][DS], vf[KT][DS];
 #pragma unroll
   for (int kk = 0; kk < KT; ++kk) {
     key[kk] = bx * (64 * KT) + wave * (16 * KT) + kk * 16 + l16;
     key_ok[kk] = key[kk] < nk;
+    tile_live[kk] = __builtin_amdgcn_readfirstlane(bx * (64 * KT) + wave * (16 * KT) + kk * 16) < nk;
 #pragma unroll
     for (int ks = 0; ks < DS; ++ks) {
       frag_from_global<T>(kf[kk][ks], Kp + (size_t)key[kk] * rs + ks * 32 + quad * 8, key_ok[kk]);
@@ -691,7 +732,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
   NatRegs<T, D> qr, gr;
   const NatSrc<T, D> qsrc(Q, p.q_rs, p.L, tid), gsrc(DO, p.o_rs, p.L, tid);
   float lse_r = 0.f, del_r = 0.f;
-  int it = 0;
   if constexpr (PF) {
     fetch_nat<T, D>(qr, qsrc, 0);
     fetch_nat<T, D>(gr, gsrc, 0);
@@ -703,10 +743,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
       ls[64 + tid] = tid < p.L ? DEL[tid] : 0.f;
     }
   }
-  for (int q0 = 0; q0 < p.L; q0 += 64) {
+  // one 64-query tile out of LDS stage CUR (compile-time: fragment addresses = per-lane offset + immediate; see forward)
+  auto tile = [&](auto cur_c, const int q0) {
+    constexpr int CUR = decltype(cur_c)::value;
     __syncthreads();
     if constexpr (PF) {
-      Qs = smem + (it & 1) * BUF;
+      Qs = smem + CUR * BUF;
       Gs = Qs + G::NAT_BYTES;
       lse_s = reinterpret_cast<float*>(Qs + 2 * G::NAT_BYTES);
       del_s = lse_s + 64;
@@ -731,59 +773,70 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
       }
       __syncthreads();
     }
-    f32x4 s[KT][4], dp[KT][4];
+    // The 64 staged queries go through in two halves of 32 (hh = the (kt >> 1) half of perm_row, which is also the
+    // reduction half of the transposed fragments): only two score tiles per key tile are live at a time, which is
+    // what lets a wave own KT = 2 key tiles -- every Q / dO fragment read from LDS then feeds two MFMAs.
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int row = perm_row(kt, l16);
+    for (int hh = 0; hh < 2; ++hh) {
+      f32x4 s[KT][2], dp[KT][2];
 #pragma unroll
-      for (int kk = 0; kk < KT; ++kk) { s[kk][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kk][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int row = perm_row(hh * 2 + k2, l16);
 #pragma unroll
-      for (int ks = 0; ks < DS; ++ks) {
-        Frag<T> a, g;
-        load_frag<T>(a, Qs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
-        load_frag<T>(g, Gs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+        for (int kk = 0; kk < KT; ++kk) { s[kk][k2] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kk][k2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int kk = 0; kk < KT; ++kk) {
-          mma16(s[kk][kt], a, kf[kk][ks]);
-          mma16(dp[kk][kt], g, vf[kk][ks]);
+        for (int ks = 0; ks < DS; ++ks) {
+          Frag<T> a, g;
+          load_frag<T>(a, Qs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+          load_frag<T>(g, Gs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+#pragma unroll
+          for (int kk = 0; kk < KT; ++kk)
+            if (tile_live[kk]) {
+              mma16(s[kk][k2], a, kf[kk][ks]);
+              mma16(dp[kk][k2], g, vf[kk][ks]);
+            }
         }
       }
-    }
-    // lane: key = l16 (column), query positions (kt>>1)*32 + quad*8 + (kt&1)*4 + i
-    Frag<T> pf[KT][2], dsf[KT][2];
+      // lane: key = l16 (column), query positions hh*32 + quad*8 + k2*4 + i
+      Frag<T> pf[KT], dsf[KT];
 #pragma unroll
-    for (int kk = 0; kk < KT; ++kk) {
-      f32x4 pr[4];
+      for (int kk = 0; kk < KT; ++kk) {
+        f32x4 pr[2];
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + hh * 32 + quad * 8 + k2 * 4);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + hh * 32 + quad * 8 + k2 * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int qp = (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
-          const float pv = key_live[kk] ? __builtin_amdgcn_exp2f(fmaf(s[kk][kt][i], c2, -lse_s[qp])) : 0.f;
-          pr[kt][i] = pv;
-          s[kk][kt][i] = pv * (dp[kk][kt][i] - del_s[qp]);
+          for (int i = 0; i < 4; ++i) {
+            const float pv = key_live[kk] ? __builtin_amdgcn_exp2f(fmaf(s[kk][k2][i], c2, -l4[i])) : 0.f;
+            pr[k2][i] = pv;
+            s[kk][k2][i] = pv * (dp[kk][k2][i] - d4[i]);
+          }
         }
-      frag_from_acc<T>(pf[kk][0], pr[0], pr[1]);
-      frag_from_acc<T>(pf[kk][1], pr[2], pr[3]);
-      frag_from_acc<T>(dsf[kk][0], s[kk][0], s[kk][1]);
-      frag_from_acc<T>(dsf[kk][1], s[kk][2], s[kk][3]);
-    }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        Frag<T> a, g;
-        load_frag_T<T, D>(g, Gs, GTs, dt, hh, quad, l16);
-        load_frag_T<T, D>(a, Qs, QTs, dt, hh, quad, l16);
-#pragma unroll
-        for (int kk = 0; kk < KT; ++kk) {
-          mma16(dv[kk][dt], g, pf[kk][hh]);
-          mma16(dk[kk][dt], a, dsf[kk][hh]);
-        }
+        frag_from_acc<T>(pf[kk], pr[0], pr[1]);
+        frag_from_acc<T>(dsf[kk], s[kk][0], s[kk][1]);
       }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        Frag<T> a, g;
+        if constexpr (PF) {
+          troff.read(g, Gs, dt, hh);
+          troff.read(a, Qs, dt, hh);
+        } else {
+          load_frag_T<T, D>(g, Gs, GTs, dt, hh, quad, l16);
+          load_frag_T<T, D>(a, Qs, QTs, dt, hh, quad, l16);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk)
+          if (tile_live[kk]) {
+            mma16(dv[kk][dt], g, pf[kk]);
+            mma16(dk[kk][dt], a, dsf[kk]);
+          }
+      }
+    }
     if constexpr (PF) {
       if (q0 + 64 < p.L) {
-        char* nb = smem + ((it + 1) & 1) * BUF;
+        char* nb = smem + (1 - CUR) * BUF;
         commit_nat<T, D>(nb, qr, tid);
         commit_nat<T, D>(nb + G::NAT_BYTES, gr, tid);
         if (tid < 64) {
@@ -792,8 +845,11 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
           ls[64 + tid] = del_r;
         }
       }
-      ++it;
     }
+  };
+  for (int q0 = 0; q0 < p.L; q0 += 128) {
+    tile(IntC<0>{}, q0);
+    if (q0 + 64 < p.L) tile(IntC<1>{}, q0 + 64);
   }
 #pragma unroll
   for (int kk = 0; kk < KT; ++kk) {
@@ -832,7 +888,10 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
   using G = AttnGeom<T, D>;
   constexpr int smem_q = sizeof(T) == 2 ? 4 * G::NAT_BYTES : 2 * G::NAT_BYTES + G::TR_BYTES;
   constexpr int smem_kv = sizeof(T) == 2 ? 2 * (2 * G::NAT_BYTES + 512) : 2 * G::NAT_BYTES + 2 * G::TR_BYTES + 512;
-  auto kkv = attn_bwd_dkv_kernel<T, D, 1>;   // 2 key tiles per wave measured SLOWER (286-331 registers -> 1 wave / SIMD)
+  // key tiles per wave of the dK / dV kernel: 2 where the registers allow it (the kernel is LDS-bandwidth bound: PMC
+  // showed 2.6 LDS instructions per MFMA at KT = 1, and every Q / dO fragment read feeds KT MFMAs)
+  constexpr int KV_KT = (sizeof(T) == 2 && D <= 64) ? 2 : 1;
+  auto kkv = attn_bwd_dkv_kernel<T, D, KV_KT>;
   // queries per wave of the dQ kernel: 32 (QT = 2) reuses each K / V fragment twice; at d = 96 its two operand sets
   // (Q, dO) + two score tiles no longer fit 256 registers, so 16 (QT = 1, three waves per SIMD) wins there
   constexpr int DQ_QT = D >= 96 ? 1 : 2;
@@ -841,7 +900,7 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
   a.delta_self_w = const_cast<float*>(a.delta_self); a.delta_cross_w = const_cast<float*>(a.delta_cross);
   a.dkc = dkc; a.dvc = dvc; a.dkc_bs = dc_bs; a.dkc_rs = dc_rs;
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, DQ_QT>), dim3((a.L + 64 * DQ_QT - 1) / (64 * DQ_QT), a.B * a.H), dim3(256), smem_q, st, a);
-  const int nself = (a.L + 63) / 64, ncross = a.kc ? (a.S + 63) / 64 : 0;
+  const int nself = (a.L + 64 * KV_KT - 1) / (64 * KV_KT), ncross = a.kc ? (a.S + 64 * KV_KT - 1) / (64 * KV_KT) : 0;
   hipLaunchKernelGGL(kkv, dim3(nself + ncross, a.B * a.H), dim3(256), smem_kv, st, a);
   MDM_LAUNCH_STATUS();
 }
