@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
+    ap.add_argument("--serial-wgrad", action="store_true",
+                    help="diagnostic: weight gradients on the main stream (uncontended per-kernel durations for profiling)")
     ap.add_argument("--no-nested", action="store_true", help="skip the nested256 (configs[2]) sub-measurement")
     ap.add_argument("--sample-batch", type=int, default=None)
     args = ap.parse_args()
@@ -187,7 +189,7 @@ def main():
         torch.cuda.synchronize()
 
     pipe, side = build(args.workload, device)
-    step = TrainStep(pipe, bf16=bf16, bucket_mb=args.bucket_mb, wire_dtype=wire)
+    step = TrainStep(pipe, bf16=bf16, bucket_mb=args.bucket_mb, wire_dtype=wire, async_wgrad=not args.serial_wgrad)
     sample = synthetic_batch(batch, side, device, seed=1234 + rank)
     dt = timed_steps(step, sample, args.warmup, args.steps, sync)
     if world > 1:

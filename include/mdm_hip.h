@@ -95,7 +95,12 @@ int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulat
  *   y = act(GN(x; gamma, beta) * (1 + film[:, :C]) + film[:, C:]),  act: 0 none, 1 SiLU
  *   stats [N][G][2] = (mean, rstd), coef [N][C][2]: saved by forward, consumed by backward.
  *   mdm_gn_bwd writes dx, dgamma[C], dbeta[C] (fp32 atomic accumulation of one term per sample: `accumulate` == 0
- *   zero-fills them first) and dfilm [N][2C] (when film != NULL).  dres (same shape as x, may be
+ *   zero-fills them first, 1 adds into them) and dfilm [N][2C] (when film != NULL).  `accumulate` == 2: dgamma / dbeta
+ *   are per-sample rows [N][C] filled with plain stores (no atomics -- at the 16x16 level the atomics of 64 samples
+ *   into the same 1536 addresses cost as much as the kernel's own traffic); mdm_gn_param_reduce_multi then adds the
+ *   rows of many layers into their gradient slots in one launch (table: DEVICE array of 48-byte descriptors
+ *   {const float* pg, pb; float* dgamma, dbeta; int N, C, first_block, pad}, first_block = prefix sum of
+ *   ceil(C / 256); total_blocks = the sum).  dres (same shape as x, may be
  *   NULL) is added into dx: the gradient that reaches x through the residual branch of the block the norm opens
  *   (h = x + f(norm(x)), unet.py:238, 309, 312) -- saves the separate accumulation kernel of the autograd engine.
  *   ws (fp32) size from mdm_gn_plan (valid for both directions).
@@ -106,6 +111,7 @@ int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, const void*
 int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* film,
                const float* stats, const float* coef, const void* dres, void* dx, float* dgamma, float* dbeta,
                void* dfilm, float* ws, int N, int HW, int C, int G, int act, int accumulate, int dtype, void* stream);
+int mdm_gn_param_reduce_multi(const void* table, int n, int total_blocks, void* stream);
 int mdm_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int R, int D, float eps,
                int dtype, void* stream);
 /* ws: fp32 [ceil(R/64)][D][2] */

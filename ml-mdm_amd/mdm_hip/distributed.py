@@ -107,6 +107,7 @@ class GradReducer:
             self._need[self._bucket_of[p]] += 1
         self._pending = list(self._need)
         self._fired = {}
+        self._deferred = set()
         self._streams = [set() for _ in self.buckets]
         self._work = []
         self._enabled = True
@@ -121,14 +122,28 @@ class GradReducer:
 
     def ready(self, p):
         if self.world > 1:
-            self._hook(self._slots[p.data_ptr()][0])
+            self._count(self._slots[p.data_ptr()][0])
+
+    def defer(self, p):
+        """the gradient of ``p`` will be reported by ready() AFTER its autograd node has returned (queued / grouped
+        weight-gradient launches, deferred GroupNorm parameter sums).  Autograd's post-accumulate hook fires when the
+        node returns -- even though the node handed back no gradient -- and must not count the parameter: the bucket
+        would be all-reduced before the gradient is written."""
+        if self.world > 1:
+            self._deferred.add(id(self._slots[p.data_ptr()][0]))
 
     def rebind(self):
         """refresh the sink lookup after the parameters' storage moved (e.g. into a flat parameter arena)"""
         self._slots = {p.data_ptr(): (p, p.grad) for p in self.params}
 
-    # -- called by autograd (or by ready()), once per parameter per backward
+    # -- autograd's post-accumulate hook: the report of every parameter whose gradient autograd itself accumulates
     def _hook(self, p):
+        if id(p) in self._deferred:
+            return
+        self._count(p)
+
+    # -- once per parameter per synchronised backward (from the hook, or from ready())
+    def _count(self, p):
         if not self._enabled:
             return
         b = self._bucket_of[p]
@@ -191,6 +206,7 @@ class GradReducer:
         self.check_bound()
         if self.world > 1 and self._enabled:
             if self._pending == self._need and not self._work:
+                self._deferred = set()
                 return  # no synchronised backward since the last finish()
             missing = [b for b, n in enumerate(self._pending) if n != 0]
             if missing:
@@ -204,6 +220,7 @@ class GradReducer:
             self._work = []
             self._pending = list(self._need)
             self._fired = {}
+        self._deferred = set()
 
     def zero_grad(self):
         self.flat.zero_()

@@ -80,6 +80,8 @@ def set_grad_sink(sink):
     kernels accumulate into the arena (C ABI ``accumulate`` flag) and return no gradient to autograd, which removes
     one ``grad += new`` kernel per parameter per step.  ``None`` restores plain autograd semantics."""
     global _grad_sink
+    if _grad_sink is not None and sink is not _grad_sink:
+        flush_wgrad_queue()   # queued work refers to the old sink's slots
     _grad_sink = sink
 
 
@@ -87,6 +89,13 @@ def _slot(param):
     if _grad_sink is None or param is None:
         return None
     return _grad_sink.slot(param)
+
+
+def _sink_defer(param):
+    """tell the sink that ready(param) will come after the autograd node returns (optional part of the protocol)"""
+    f = getattr(_grad_sink, "defer", None)
+    if f is not None and param is not None:
+        f(param)
 
 
 # Weight gradients are off the critical path of backward (nothing downstream reads them before the optimizer), so
@@ -182,6 +191,9 @@ def _queue_wgrad(x, dy, weight, bias, slot, bslot, M, cin, cout):
     key = (M, cin, cout, x.device.index)
     q = _wgrad_queue.setdefault(key, [])
     q.append((x, dy, weight, bias, slot, bslot))
+    _sink_defer(weight)
+    if bslot is not None:
+        _sink_defer(bias)
     if len(q) == _WG_MAX:
         _flush_key(key)
 
@@ -223,6 +235,63 @@ def flush_wgrad_queue():
     """launch every queued weight gradient (call at resolution-level boundaries and before the optimizer)"""
     for key in list(_wgrad_queue):
         _flush_key(key)
+    flush_gn_params()
+
+
+# --------------------------------------------------------------------------------------
+# deferred GroupNorm parameter gradients
+# --------------------------------------------------------------------------------------
+# dgamma / dbeta of a GroupNorm are sums over the batch of per-sample terms.  Adding them into the gradient slot with
+# atomics from inside the backward kernel costs as much as the kernel itself at the 16x16 level (64 samples x 1536
+# addresses on two memory channels: 45 us against 24 us); a reduce kernel per layer is ~100 tiny launches per step.
+# With the sink installed nothing reads these gradients before the optimizer, so the kernels store per-sample rows
+# into a pooled buffer and ONE launch per flush point (mdm_gn_param_reduce_multi) adds the rows of every pending layer
+# into their slots -- in a fixed order, so the result is deterministic as well.
+_gn_pending = []     # (pg, pb, slot_g, slot_b, N, C, gamma, beta)
+_gn_pool = {}        # device index -> [buffer (fp32), offset, high-water mark of the current step]
+_gn_tables = {}      # tuple of (pointers, sizes) -> device descriptor table
+
+
+def _gn_rows(N, C, device):
+    """two [N, C] fp32 row blocks out of the pool (the same addresses every step: the descriptor table is reused)"""
+    ent = _gn_pool.get(device.index)
+    need = 2 * N * C
+    if ent is None or ent[1] + need > ent[0].numel():
+        # grow: pending entries keep their old buffer alive through the tensors they hold
+        size = max(need, 0 if ent is None else 2 * ent[0].numel(), 16 << 20)
+        ent = _gn_pool[device.index] = [torch.empty(size, dtype=torch.float32, device=device), 0]
+    off = ent[1]
+    ent[1] = off + need
+    return ent[0][off:off + N * C], ent[0][off + N * C:off + need]
+
+
+def flush_gn_params():
+    """add the pending per-sample GroupNorm parameter-gradient rows into their gradient slots (one launch)"""
+    if not _gn_pending:
+        return
+    dev = _gn_pending[0][0].device
+    key = tuple((e[0].data_ptr(), e[1].data_ptr(), e[2].data_ptr(), e[3].data_ptr(), e[4], e[5]) for e in _gn_pending)
+    ent = _gn_tables.get(key)
+    if ent is None:
+        import numpy as np
+        rec = np.zeros(len(key), dtype=[("pg", "<u8"), ("pb", "<u8"), ("dg", "<u8"), ("db", "<u8"), ("N", "<i4"),
+                                         ("C", "<i4"), ("first", "<i4"), ("pad", "<i4")])
+        blocks = 0
+        for i, (pg, pb, dg, db, N, C) in enumerate(key):
+            rec[i] = (pg, pb, dg, db, N, C, blocks, 0)
+            blocks += (C + 255) // 256
+        table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        if len(_gn_tables) > 64:
+            _gn_tables.clear()
+        ent = _gn_tables[key] = (table, blocks)
+    table, blocks = ent
+    _lib.check(_lib.lib().mdm_gn_param_reduce_multi(_p(table), len(key), blocks, _stream()), "mdm_gn_param_reduce_multi")
+    for e in _gn_pending:
+        _grad_sink.ready(e[6])
+        _grad_sink.ready(e[7])
+    _gn_pending.clear()
+    for ent in _gn_pool.values():
+        ent[1] = 0   # the next rows are written by kernels queued behind the reduce on the same stream
 
 
 class _FlushPointFn(torch.autograd.Function):
@@ -682,15 +751,25 @@ class GroupNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         sg, sb = _slot(gamma), _slot(beta)
         sunk = sg is not None and sb is not None
-        dgamma = sg if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
-        dbeta = sb if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
+        deferred = sunk and _defer_wgrad   # per-sample rows now, one multi-layer reduce at the next flush point
+        if deferred:
+            dgamma, dbeta = _gn_rows(N, C, x.device)
+        else:
+            dgamma = sg if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
+            dbeta = sb if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
         dfilm = torch.empty_like(film) if film is not None else None
         ws = _gn_ws(N, HW, C, ctx.groups, x.device)
+        mode = 2 if deferred else (1 if sunk else 0)
         _prof_wrap("group_norm bwd (HW=%d)" % HW, (4.0 if dres is not None else 3.0) * x.numel() * x.element_size(), lambda: _lib.check(
             _lib.lib().mdm_gn_bwd(_p(dy), _p(x), _p(g32), _p(b32), _p(film), _p(stats), _p(coef), _p(dres), _p(dx), _p(dgamma),
-                                  _p(dbeta), _p(dfilm), _p(ws), N, HW, C, ctx.groups, ctx.act, 1 if sunk else 0, _dt(x), _stream()),
+                                  _p(dbeta), _p(dfilm), _p(ws), N, HW, C, ctx.groups, ctx.act, mode, _dt(x), _stream()),
             "mdm_gn_bwd",
         ), kind="hbm")
+        if deferred:
+            _gn_pending.append((dgamma, dbeta, sg, sb, N, C, gamma, beta))
+            _sink_defer(gamma)
+            _sink_defer(beta)
+            return dx, None, None, dfilm, None, None, None, None
         if sunk:
             _grad_sink.ready(gamma)
             _grad_sink.ready(beta)

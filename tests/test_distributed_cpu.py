@@ -85,6 +85,8 @@ class _SinkLinear(torch.autograd.Function):
     """stands in for the HIP ops under a gradient sink: the weight / bias gradients are ADDED into the reducer's arena
     slots from inside backward, reported with ready(), and autograd gets None back (mdm_hip.ops.ConvFn.backward)"""
     sink = None
+    deferred = False     # queue the gradient and report it after backward (grouped weight gradients, GroupNorm sums)
+    queue = []
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -95,14 +97,29 @@ class _SinkLinear(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, b = ctx.saved_tensors
         s = _SinkLinear.sink
+        if _SinkLinear.deferred:
+            s.defer(w)
+            s.defer(b)
+            _SinkLinear.queue.append((w, b, dy.t() @ x, dy.sum(0)))
+            return dy @ w, None, None
         s.slot(w).add_(dy.t() @ x)
         s.slot(b).add_(dy.sum(0))
         s.ready(w)
         s.ready(b)
         return dy @ w, None, None
 
+    @staticmethod
+    def flush():
+        s = _SinkLinear.sink
+        for w, b, dw, db in _SinkLinear.queue:
+            s.slot(w).add_(dw)
+            s.slot(b).add_(db)
+            s.ready(w)
+            s.ready(b)
+        _SinkLinear.queue.clear()
 
-def _sink_worker(rank, world, port, out):
+
+def _sink_worker(rank, world, port, out, deferred=False):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml-mdm_amd"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from mdm_hip import distributed as md
@@ -112,6 +129,7 @@ def _sink_worker(rank, world, port, out):
     lin = [m for m in model if isinstance(m, nn.Linear)]
     red = md.GradReducer(list(model.parameters()), bucket_mb=0.002, tail_mb=0.005)
     _SinkLinear.sink = red
+    _SinkLinear.deferred = deferred
 
     def fwd(x):
         for i, m in enumerate(lin):
@@ -126,7 +144,9 @@ def _sink_worker(rank, world, port, out):
     for step in range(2):               # two optimizer steps, each = one no_sync micro-step + one synchronised one
         with red.no_sync():
             ((fwd(xs) - ys) ** 2).mean().backward()
+            _SinkLinear.flush()
         ((fwd(xs) - ys) ** 2).mean().backward()
+        _SinkLinear.flush()
         red.finish()
         flat = red.flat.clone()
         red.zero_grad()
@@ -136,12 +156,15 @@ def _sink_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_sink_mode_with_accumulation_gloo_world2(tmp_path):
+@pytest.mark.parametrize("deferred", [False, True])
+def test_sink_mode_with_accumulation_gloo_world2(tmp_path, deferred):
     """the gradient-sink reporting path (ready() from inside backward, no autograd gradient) through no_sync
     accumulation and several buckets incl. the small tail bucket: every bucket fires exactly once per synchronised
-    backward and finish() returns the rank average of the accumulated gradients"""
+    backward and finish() returns the rank average of the accumulated gradients.  deferred: the gradient is written
+    and reported AFTER backward (defer() + ready()); autograd's hook, which fires when the node returns, must not
+    release the bucket early."""
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_sink_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_sink_worker, args=(2, _free_port(), out, deferred), nprocs=2, join=True)
     got = torch.load(out)
     model = _model(seed=0)
     g = torch.Generator().manual_seed(100)

@@ -27,18 +27,18 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _batch():
+def _batch(side=16):
     g = torch.Generator().manual_seed(77)
     return {
-        "images": torch.rand(4, 3, 16, 16, generator=g) * 2 - 1,
+        "images": torch.rand(4, 3, side, side, generator=g) * 2 - 1,
         "lm_outputs": torch.randn(4, 8, 64, generator=g),
         "lm_mask": torch.ones(4, 8),
         "time": torch.tensor([10, 300, 650, 990]),
-        "noise": torch.randn(4, 3, 16, 16, generator=g),
+        "noise": torch.randn(4, 3, side, side, generator=g),
     }
 
 
-def _run_step(sel, steps=2):
+def _run_step(sel, steps=2, side=16, bf16=False, async_wgrad=True):
     _setup_paths()
     import parity_cases as PC
     from mdm_hip import diffusion as D
@@ -51,36 +51,61 @@ def _run_step(sel, steps=2):
     scfg = S.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
                            loss_target_type="DDPM")
     pipe = D.Diffusion(model, D.DiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False)).to(torch.device("cuda:0"))
-    step = TrainStep(pipe, bf16=False, lr=1e-3, clip_norm=1e9, fused=True, bucket_mb=4.0)
-    b = _batch()
+    step = TrainStep(pipe, bf16=bf16, lr=1e-3, clip_norm=1e9, fused=True, bucket_mb=0.25, async_wgrad=async_wgrad)
+    b = _batch(side)
     smp = {k: b[k][sel].cuda() for k in ("images", "lm_outputs", "lm_mask")}
     noise = b["noise"][sel].cuda()
     for _ in range(steps):
         step(smp, time=b["time"][sel].cuda(), noise_fn=lambda like: noise)
     torch.cuda.synchronize()
     ops.set_grad_sink(None)
+    if bf16:
+        # Adam's first step is lr * sign(g): parameters after it magnify bf16 rounding noise wherever g ~ 0.  The first
+        # moment after ONE step is (1 - beta1) * (rank-averaged gradient): linear in what the reducer produced.
+        return {"m": step.m.detach().float().cpu().clone()}
     return {k: v.detach().float().cpu().clone() for k, v in model.named_parameters()}
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, side, bf16, async_wgrad=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     _setup_paths()
     import torch.distributed as dist
     from mdm_hip import distributed as md
 
     md.init_distributed_singlenode(backend="gloo")
-    params = _run_step(slice(rank * 2, rank * 2 + 2))
+    params = _run_step(slice(rank * 2, rank * 2 + 2), steps=1 if bf16 else 2, side=side, bf16=bf16, async_wgrad=async_wgrad)
     if rank == 0:
         torch.save(params, out)
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _rel(a, b):
+    num = sum(float((a[k].double() - b[k].double()).pow(2).sum()) for k in b)
+    den = sum(float(b[k].double().pow(2).sum()) for k in b)
+    return (num / den) ** 0.5
+
+
 def test_two_rank_train_step_matches_single_process(tmp_path):
+    """fp32: two ranks x 2 samples == one process x 4 samples (parameters after two optimizer steps).  The GroupNorm
+    parameter gradients take the deferred route (per-sample rows + one reduce per flush point, reported to the
+    reducer after their autograd node returned), in many small buckets."""
     out = str(tmp_path / "p.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, 16, False), nprocs=2, join=True)
     two = torch.load(out)
     one = _run_step(slice(0, 4))
-    num = sum(float((two[k].double() - one[k].double()).pow(2).sum()) for k in one)
-    den = sum(float(one[k].double().pow(2).sum()) for k in one)
-    assert (num / den) ** 0.5 < 1e-4
+    assert _rel(two, one) < 1e-4
+
+
+def test_two_rank_deferred_weight_gradients_bf16(tmp_path):
+    """bf16 at 128 x 128: 2 x 64 x 64 = 8192 pixels per rank at the attention level, so the 1x1 weight gradients take
+    the QUEUED route (launched at flush points, reported after their autograd node returned).  A bucket released by
+    autograd's own hook before those gradients were written would change the reduced gradient; compared with the same
+    two-rank step without side stream / queue / deferral (same batch split, so bf16 rounding is the same -- against a
+    single process the batch-size-dependent reduction orders alone move a bf16 gradient by ~1e-2)."""
+    res = []
+    for async_wgrad in (True, False):
+        out = str(tmp_path / ("p%d.pt" % async_wgrad))
+        mp.spawn(_worker, args=(2, _free_port(), out, 128, True, async_wgrad), nprocs=2, join=True)
+        res.append(torch.load(out))
+    assert _rel(res[0], res[1]) < 1e-4

@@ -509,3 +509,54 @@ def test_fails_loudly_without_gpu_tensor():
 
     with pytest.raises(_lib.MdmHipError):
         ops.silu(torch.randn(4, 8))
+
+
+@pytest.mark.parametrize("H,C,film", [(16, 768, False), (16, 1536, True), (32, 512, True), (64, 256, False)])
+def test_deferred_group_norm_param_grads_equal_atomic_path(H, C, film):
+    """with the gradient sink + deferral the GroupNorm backward stores per-sample rows and ONE multi-layer reduce adds
+    them into the slots (flush point / end of backward) == the immediate atomic accumulation; two steps, so the pooled
+    rows and the cached descriptor table are reused"""
+    from mdm_hip import ops
+
+    class Sink:
+        def __init__(self, params):
+            self.slots = {p.data_ptr(): torch.full_like(p, 0.5) for p in params}   # non-zero: the reduce ADDS
+            self.seen = []
+
+        def slot(self, p):
+            return self.slots.get(p.data_ptr())
+
+        def ready(self, p):
+            self.seen.append(p.data_ptr())
+
+    g = torch.Generator().manual_seed(5)
+    N, L = 6, 3
+    gam = [(1 + 0.1 * torch.randn(C, generator=g)).to(dev()).requires_grad_() for _ in range(L)]
+    bet = [(0.1 * torch.randn(C, generator=g)).to(dev()).requires_grad_() for _ in range(L)]
+    x0 = torch.randn(N, H, H, C, generator=g).to(dev()).to(torch.bfloat16)
+    fl = (0.2 * torch.randn(N, 2 * C, generator=g)).to(dev()).to(torch.bfloat16) if film else None
+    out = []
+    for deferred in (False, True):
+        sink = Sink(gam + bet)
+        ops.set_grad_sink(sink)
+        ops.enable_deferred_wgrad(deferred)
+        for step in range(2):
+            x = x0.clone().requires_grad_()
+            f = fl.clone().requires_grad_() if film else None
+            h = x
+            for i in range(L):
+                h = ops.group_norm(h, gam[i], bet[i], 32, film=f, silu=(i % 2 == 0))
+                if i == 0:
+                    h = ops.wgrad_flush_point(h)
+            h.float().square().mean().backward()
+            ops.flush_wgrad_queue()
+        torch.cuda.synchronize()
+        assert sorted(sink.seen) == sorted([p.data_ptr() for p in gam + bet] * 2)
+        out.append(([sink.slots[p.data_ptr()].clone() for p in gam + bet], x.grad.clone(), f.grad.clone() if film else None))
+    ops.set_grad_sink(None)
+    ops.enable_deferred_wgrad(False)
+    for a, b in zip(out[0][0], out[1][0]):
+        assert relerr(b, a) < 1e-5          # atomic order vs fixed order
+    assert torch.equal(out[0][1], out[1][1])
+    if film:
+        assert torch.equal(out[0][2], out[1][2])

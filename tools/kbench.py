@@ -87,6 +87,44 @@ def main():
             fl = 2.0 * G * M * cin * cout
             t1 = timeit(lambda: [ops._wgrad_launch(xs[i].view(B, H, H, cin), dys[i].view(B, H, H, cout), B, H, H, cin, H, H, cout, 1, 1, out=dws[i], dbias=dbs[i]) for i in range(G)], iters=3)
             print("%-22s grouped x%d %7.3f ms %7.1f TF   one-by-one (split + reduce) %7.3f ms %7.1f TF" % (name, G, t * 1e3, fl / t / 1e12, t1 * 1e3, fl / t1 / 1e12), flush=True)
+    if what in ("gn",):
+        # GroupNorm(+SiLU) forward / backward at the shapes of the cc12m_64x64 U-Net: achieved GB/s over the minimal
+        # traffic (fwd: read x + write y; bwd: read dy, x + write dx)
+        for H, C in ((64, 256), (64, 512), (32, 512), (32, 768), (32, 1024), (32, 1280), (16, 768), (16, 1280), (16, 1536)):
+            x = torch.randn(B, H, H, C, device=dev).to(DT).requires_grad_()
+            gam = torch.randn(C, device=dev).requires_grad_()
+            bet = torch.randn(C, device=dev).requires_grad_()
+            t = timeit(lambda: ops.group_norm(x.detach(), gam.detach(), bet.detach(), 32, silu=True))
+            y = ops.group_norm(x, gam, bet, 32, silu=True)
+            gy = torch.randn_like(y)
+            tb = timeit(lambda: torch.autograd.grad(y, (x, gam, bet), gy, retain_graph=True))
+            nb = x.numel() * x.element_size()
+            # the backward kernel(s) alone, launched directly (no autograd / Python between launches)
+            from mdm_hip import _lib
+            film = None
+            stats = torch.empty((B, 32, 2), dtype=torch.float32, device=dev)
+            coef = torch.empty((B, C, 2), dtype=torch.float32, device=dev)
+            ws = ops._gn_ws(B, H * H, C, 32, dev)
+            yy = torch.empty_like(x)
+            xd = x.detach()
+            _lib.check(_lib.lib().mdm_gn_fwd(ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(yy), ops._p(stats), ops._p(coef), ops._p(ws), B, H * H, C, 32, 1e-5, 1, ops._dt(xd), ops._stream()), "fwd")
+            gmode = int(os.environ.get('KB_GN_MODE', '2'))   # 2: per-sample rows (deferred reduce), 1: atomics into a slot
+            dxx = torch.empty_like(xd); dg = torch.zeros(B if gmode == 2 else 1, C, device=dev); db = torch.zeros_like(dg)
+            def direct():
+                _lib.check(_lib.lib().mdm_gn_bwd(ops._p(gy), ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(stats), ops._p(coef), None, ops._p(dxx), ops._p(dg), ops._p(db), None, ops._p(ws), B, H * H, C, 32, 1, gmode, ops._dt(xd), ops._stream()), "bwd")
+            def directf():
+                _lib.check(_lib.lib().mdm_gn_fwd(ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(yy), ops._p(stats), ops._p(coef), ops._p(ws), B, H * H, C, 32, 1e-5, 1, ops._dt(xd), ops._stream()), "fwd")
+            for f in (direct, directf):
+                for _ in range(3): f()
+            e0, e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50): direct()
+            e1.record()
+            for _ in range(50): directf()
+            e2.record()
+            torch.cuda.synchronize()
+            tb, t = e0.elapsed_time(e1) / 50e3, e1.elapsed_time(e2) / 50e3
+            print("gn %dx%d C=%-5d (%6.1f MB)  fwd %7.3f ms %6.0f GB/s   bwd %7.3f ms %6.0f GB/s" % (H, H, C, nb / 1e6, t * 1e3, 2 * nb / t / 1e9, tb * 1e3, 3 * nb / tb / 1e9), flush=True)
     if what in ("attn", "all"):
         for L, d in ((1024, 64), (256, 96)):
             C = 8 * d
