@@ -1548,32 +1548,44 @@ struct PackDesc {
 
 template <typename T, int TAPS>
 __device__ __forceinline__ void pack_brick(const PackDesc& d, int brick, float (*tile)[32 * 9 + 1]) {
+  // 16-byte global accesses on both sides: float4 loads of the brick's 32 rows (32 * TAPS contiguous floats each),
+  // V = 16 / sizeof(T) packed elements per store (runs of 32 output elements are contiguous in both packs: channel
+  // bricks are 32-aligned and the k-blocks are multiples of 32)
+  constexpr int V = 16 / (int)sizeof(T), NV = 32 / V;
   const int ibn = d.Cin / 32;
   const int ib = (brick % ibn) * 32, ob = (brick / ibn) * 32;
   const int tid = threadIdx.x;
   const int Cin = d.Cin, Cout = d.Cout;
-  for (int e = tid; e < 32 * 32 * TAPS; e += 256) {
-    const int ol = e / (32 * TAPS), r = e - ol * (32 * TAPS);
-    tile[ol][r] = d.w[((size_t)(ob + ol) * Cin + ib) * TAPS + r];
+  for (int e = tid; e < 32 * 8 * TAPS; e += 256) {
+    const int ol = e / (8 * TAPS), q = e - ol * (8 * TAPS);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(d.w + ((size_t)(ob + ol) * Cin + ib) * TAPS + q * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[ol][q * 4 + j] = v[j];
   }
   __syncthreads();
   const size_t Kf = (size_t)TAPS * Cin, Kd = (size_t)TAPS * Cout;
   T* wf = reinterpret_cast<T*>(d.wf);
   T* wd = reinterpret_cast<T*>(d.wd);
-  for (int e = tid; e < 32 * TAPS * 32; e += 256) {
-    const int il = e & 31, rest = e >> 5;
+  for (int e = tid; e < 32 * TAPS * NV; e += 256) {
+    const int iv = e % NV, rest = e / NV;
     const int tp = rest % TAPS, ol = rest / TAPS;
-    const int i = ib + il;
+    const int i = ib + iv * V;
     const size_t kpos = d.kbf ? (size_t)(i / d.kbf) * TAPS * d.kbf + (size_t)tp * d.kbf + (i % d.kbf) : (size_t)tp * Cin + i;
-    wf[(size_t)(ob + ol) * Kf + kpos] = from_f32<T>(tile[ol][il * TAPS + tp]);
+    T out[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) out[j] = from_f32<T>(tile[ol][(iv * V + j) * TAPS + tp]);
+    *reinterpret_cast<uint4*>(wf + (size_t)(ob + ol) * Kf + kpos) = *reinterpret_cast<const uint4*>(out);
   }
   if (wd) {
-    for (int e = tid; e < 32 * TAPS * 32; e += 256) {
-      const int ol = e & 31, rest = e >> 5;
+    for (int e = tid; e < 32 * TAPS * NV; e += 256) {
+      const int ov = e % NV, rest = e / NV;
       const int tp = rest % TAPS, il = rest / TAPS;
-      const int o = ob + ol;
+      const int o = ob + ov * V;
       const size_t kpos = d.kbd ? (size_t)(o / d.kbd) * TAPS * d.kbd + (size_t)tp * d.kbd + (o % d.kbd) : (size_t)tp * Cout + o;
-      wd[(size_t)(ib + il) * Kd + kpos] = from_f32<T>(tile[ol][il * TAPS + (TAPS - 1 - tp)]);
+      T out[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) out[j] = from_f32<T>(tile[ov * V + j][il * TAPS + (TAPS - 1 - tp)]);
+      *reinterpret_cast<uint4*>(wd + (size_t)(ib + il) * Kd + kpos) = *reinterpret_cast<const uint4*>(out);
     }
   }
 }

@@ -560,3 +560,27 @@ def test_deferred_group_norm_param_grads_equal_atomic_path(H, C, film):
     assert torch.equal(out[0][1], out[1][1])
     if film:
         assert torch.equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_repack_all_matches_single_weight_pack(dtype):
+    """the optimizer tail's one-launch re-pack (mdm_pack_weights_multi: 32x32xtaps bricks, 16-byte loads and stores)
+    == the per-weight pack, for 1x1 and 3x3 weights incl. the block-major 3x3 reduction order"""
+    from mdm_hip import ops
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 32, 1, 1), (96, 160, 1, 1), (128, 64, 3, 3), (64, 192, 3, 3), (256, 256, 3, 3), (32, 32, 3, 3)]
+    ws = [torch.randn(*s, generator=g).to(dev()) for s in shapes]
+    ops._wcache.clear()
+    for w in ws:
+        ops.packed_weight(w, None, dtype)
+    for w in ws:                       # an optimizer step: new values, same storage
+        w.mul_(0.5).add_(1.0)
+    ops.repack_all(dtype)
+    multi = [[t.clone() if t is not None else None for t in ops.packed_weight(w, None, dtype)[:2]] for w in ws]
+    ops._wcache.clear()
+    for w, m in zip(ws, multi):
+        single = ops.packed_weight(w, None, dtype)[:2]
+        for a, b in zip(m, single):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b), tuple(w.shape)

@@ -87,6 +87,32 @@ def main():
             fl = 2.0 * G * M * cin * cout
             t1 = timeit(lambda: [ops._wgrad_launch(xs[i].view(B, H, H, cin), dys[i].view(B, H, H, cout), B, H, H, cin, H, H, cout, 1, 1, out=dws[i], dbias=dbs[i]) for i in range(G)], iters=3)
             print("%-22s grouped x%d %7.3f ms %7.1f TF   one-by-one (split + reduce) %7.3f ms %7.1f TF" % (name, G, t * 1e3, fl / t / 1e12, t1 * 1e3, fl / t1 / 1e12), flush=True)
+    if what in ("pack",):
+        # the optimizer tail's re-pack of every kernel-layout weight (ops.repack_all) on a UNet-64-like weight set
+        shapes = [((256, 256, 3, 3), 7), ((512, 512, 3, 3), 6), ((768, 768, 3, 3), 10), ((256, 512, 3, 3), 3), ((512, 768, 3, 3), 1),
+                  ((512, 1024, 3, 3), 2), ((512, 1280, 3, 3), 1), ((768, 1280, 3, 3), 1), ((768, 1536, 3, 3), 3),
+                  ((2304, 768, 1, 1), 26), ((768, 768, 1, 1), 26), ((3072, 768, 1, 1), 26), ((768, 3072, 1, 1), 26),
+                  ((1536, 512, 1, 1), 5), ((512, 512, 1, 1), 5), ((2048, 512, 1, 1), 5), ((512, 2048, 1, 1), 5)]
+        ws = [torch.randn(*sh, device=dev) for sh, cnt in shapes for _ in range(cnt)]
+        for w in ws:
+            ops.packed_weight(w, None, DT)
+        n = sum(w.numel() for w in ws)
+        for _ in range(2):
+            ops.repack_all(DT)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.repack_all(DT)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 10e3
+        print("pack %d weights, %.1f M parameters: %.3f ms  %.0f GB/s (4 B read + 2 x 2 B written per parameter)" % (len(ws), n / 1e6, t * 1e3, 8.0 * n / t / 1e9), flush=True)
+        # spot check against the single-weight pack
+        w = ws[0]
+        a = [t_.clone() for t_ in ops.packed_weight(w, None, DT)[:2]]
+        ops._wcache.clear()
+        b = ops.packed_weight(w, None, DT)[:2]
+        print("pack matches single-weight pack:", all(torch.equal(x_, y_) for x_, y_ in zip(a, b)), flush=True)
     if what in ("gn",):
         # GroupNorm(+SiLU) forward / backward at the shapes of the cc12m_64x64 U-Net: achieved GB/s over the minimal
         # traffic (fwd: read x + write y; bwd: read dy, x + write dx)
