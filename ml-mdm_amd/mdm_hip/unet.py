@@ -398,7 +398,14 @@ class UNet(nn.Module):
 
     def load(self, fname: str):
         """Non-strict load on the key intersection; returns the non-weight items (unet.py:802-832)."""
-        ckpt = torch.load(fname, map_location="cpu", weights_only=False)
+        # tensors-only unpickling first; the reference's checkpoints may carry plain-Python extras that need the full
+        # unpickler (reference unet.py:803 uses it unconditionally) -- which executes code from the file: trusted files only
+        try:
+            ckpt = torch.load(fname, map_location="cpu", weights_only=True)
+        except Exception:
+            if os.environ.get("MDM_HIP_SAFE_LOAD", "0") == "1":
+                raise
+            ckpt = torch.load(fname, map_location="cpu", weights_only=False)
         mine = self.state_dict()
         theirs = ckpt["state_dict"]
         common = {k: v for k, v in theirs.items() if k in mine}
