@@ -87,10 +87,10 @@ class GraphedSampler:
     """``Diffusion.sample`` / ``NestedDiffusion.sample`` with one hipGraph replay per denoise step.
 
     Semantics are those of ``Sampler._sample`` with ``resample_steps=True`` (reference samplers.py:516-609, 655-713):
-    DDPM (``ddim_eta=None``) or DDIM(eta), classifier-free guidance, CLIP / NONE thresholding.  The ancestral noise
-    comes from the library's counter-based generator (``ops.DeviceRng``, replayable on the host); the START noise is
-    drawn like the eager path (CPU generator for the top scale, reference diffusion.py:177), or passed in.
-    Dynamic thresholding needs a quantile between two kernels and stays on the eager sampler."""
+    DDPM (``ddim_eta=None``) or DDIM(eta), classifier-free guidance, CLIP / NONE / DYNAMIC / DYNAMIC_IF thresholding (the
+    dynamic ones: x0 kernel -> ``torch.quantile`` -> update kernel, all inside the graph).  The ancestral noise comes
+    from the library's counter-based generator (``ops.DeviceRng``, replayable on the host); the START noise is drawn
+    like the eager path (CPU generator for the top scale, reference diffusion.py:177), or passed in."""
 
     def __init__(self, pipeline, warmup: int = 2, seed: int = 0):
         self.pipe = pipeline
@@ -99,8 +99,8 @@ class GraphedSampler:
         self._seed = seed
         self._graphs = {}
         fn = self.sampler._config.threshold_function
-        if fn not in (ThresholdType.CLIP, ThresholdType.NONE):
-            raise NotImplementedError("GraphedSampler: dynamic thresholding needs the eager sampler")
+        if fn not in (ThresholdType.CLIP, ThresholdType.NONE, ThresholdType.DYNAMIC, ThresholdType.DYNAMIC_IF):
+            raise NotImplementedError("GraphedSampler: unknown threshold function %r" % (fn,))
 
     def reset(self):
         self._graphs.clear()
@@ -132,7 +132,12 @@ class GraphedSampler:
         ce, cs, cm = vm.forward_conditioning(cond, mask)
         ce_s, cs_s, cm_s = ce.clone(), cs.clone(), (cm.clone() if cm is not None else None)
         out_scale = model._output_scale
-        clip = "CLIP" if cfg.threshold_function == ThresholdType.CLIP else "NONE"
+        fn = cfg.threshold_function
+        clip = {ThresholdType.CLIP: "CLIP", ThresholdType.NONE: "NONE"}.get(fn, "DYNAMIC")
+        # Imagen dynamic thresholding (samplers.py:461-498): a per-sample quantile of |x0| sits between two launches of
+        # the step kernel (x0 only, then the update with the threshold) -- torch.quantile is a sort + lerp on the
+        # device, so it is captured with the rest
+        dyn = {ThresholdType.DYNAMIC: (0.995, 100.0), ThresholdType.DYNAMIC_IF: (0.95, 1.5)}.get(fn)
         noisy = not (ddim_eta is not None and ddim_eta <= 0)
 
         def body():
@@ -159,8 +164,13 @@ class GraphedSampler:
                 if guidance != 1:
                     pu, p = p.chunk(2)
                 img_scale = (sc if not cfg.schedule_shifted else 1) if nested else (cfg.rescale_signal or 1)
+                thr = None
+                if dyn is not None:
+                    x0s, _ = ops.sampler_step(x, p, g_t[i], g_s[i], cfg.prediction_type, ddim_eta=ddim_eta, clip="X0_ONLY",
+                                              image_scale=img_scale, pred_uncond=pu, guidance_scale=guidance)
+                    thr = torch.quantile(x0s.reshape(B, -1).abs(), dyn[0], dim=1).clamp(min=1, max=dyn[1])
                 _, x_last = ops.sampler_step(x, p, g_t[i], g_s[i], cfg.prediction_type, ddim_eta=ddim_eta, need_noise=noisy,
-                                             rng=rng, clip=clip, image_scale=img_scale, pred_uncond=pu,
+                                             rng=rng, clip=clip, thr=thr, image_scale=img_scale, pred_uncond=pu,
                                              guidance_scale=guidance, noise_gate=gate)
                 if noisy:
                     rng.advance(x.numel())   # same draw order as the eager sampler with use_device_rng()

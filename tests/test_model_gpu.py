@@ -85,13 +85,13 @@ def test_no_grad_inference_matches_training_forward():
     assert torch.equal(y.float().cpu(), ref[0])
 
 
-def _pipeline(name, net):
+def _pipeline(name, net, threshold="CLIP"):
     from mdm_hip import diffusion as D
     from mdm_hip import samplers as S
 
     nested = name == "mini_nested"
     scfg = S.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
-                           loss_target_type="DDPM", threshold_function="CLIP", schedule_shifted=nested,
+                           loss_target_type="DDPM", threshold_function=threshold, schedule_shifted=nested,
                            rescale_signal=1 if nested else None)
     if nested:
         return D.NestedDiffusion(net, D.NestedDiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False,
@@ -387,7 +387,7 @@ def test_graph_replay_matches_eager(name):
 
 
 @pytest.mark.parametrize("name", ["mini_unet", "mini_nested"])
-@pytest.mark.parametrize("mode", ["ddim", "ddpm_cfg"])
+@pytest.mark.parametrize("mode", ["ddim", "ddpm_cfg", "ddpm_dynamic"])
 def test_graphed_sampler_matches_eager_sampler(name, mode):
     """GraphedSampler (one hipGraph replay per WHOLE denoise iteration: schedule lookup, denoiser, fused update of every
     scale, RNG / step-counter advance) == the eager sampler on the same start noise; DDPM mode draws its noise inside
@@ -395,11 +395,11 @@ def test_graphed_sampler_matches_eager_sampler(name, mode):
     from mdm_hip.graph import GraphedSampler
 
     model, _, _ = PC.build_module(name)
-    pipe = _pipeline(name, model).to(torch.device("cuda:0"))
+    pipe = _pipeline(name, model, threshold="DYNAMIC_IF" if mode == "ddpm_dynamic" else "CLIP").to(torch.device("cuda:0"))
     pipe.eval()
     inp = PC.inputs(name)
     cond, mask = inp["cond"].cuda(), inp["mask"].cuda()
-    kw = dict(ddim_eta=0) if mode == "ddim" else dict(ddim_eta=None, guidance_scale=2.5)
+    kw = dict(ddim_eta=0) if mode == "ddim" else dict(ddim_eta=None, guidance_scale=2.5 if mode == "ddpm_cfg" else 1)
     if mode == "ddpm_cfg":
         cond, mask = torch.cat([torch.zeros_like(cond), cond]), torch.cat([mask, mask])
     smp = {"lm_outputs": cond, "lm_mask": mask}
