@@ -32,6 +32,17 @@ SHAPES = [
 ]
 
 
+if os.environ.get("KB_SET") == "nested":   # the outer (256 x 256, 64 / 128 channel) levels of the nested 64+256 model; use KB_BATCH=16
+    SHAPES = [
+        ("3x3 64->64 @256", 256, 64, 64, 3, 1),
+        ("3x3 128->64 @256", 256, 128, 64, 3, 1),
+        ("3x3 64->128 @128", 128, 64, 128, 3, 1),
+        ("3x3 128->128 @128", 128, 128, 128, 3, 1),
+        ("3x3 256->128 @128", 128, 256, 128, 3, 1),
+        ("1x1 128->64 @256", 256, 128, 64, 1, 1),
+    ]
+
+
 def timeit(fn, iters=10):
     fn()
     torch.cuda.synchronize()
