@@ -742,10 +742,14 @@ __global__ __launch_bounds__(256) void ln_multi_param_kernel(LnGroup g, const T*
 
 using namespace mdm;
 
+// pixel slabs of the partial-sum stage: about 1024 blocks in total, but never more than 32 per sample -- every block of
+// the apply stage adds up the slabs of its channels serially (one dependent L2 load each: 256 slabs at batch 4 made a
+// 64 x 64 norm take 71 us, 8x its batch-64 cost per byte)
 static inline int gn_slabs(int N, int HW) {
   int s = (1024 + N - 1) / N;
   const int max_s = (HW + 15) / 16;
   if (s > max_s) s = max_s;
+  if (s > 32) s = 32;
   if (s < 1) s = 1;
   return s;
 }
