@@ -68,6 +68,14 @@ int mdm_pack_weights_multi(const void* table, int n, int total_blocks, int dtype
 int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const void* res, const void* aux, void* y,
                  void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride,
                  int transposed, int act, int kblock, int dtype, void* stream);
+/* Small problems (sampling at batch 1-4): when the output tiles cannot fill the chip the reduction is split over more
+ * blocks -- partial fp32 tiles in `ws`, then one sum + epilogue launch (same rounding points as the fused epilogue).
+ * mdm_conv_fwd_plan: splits (1 = none) and the workspace bytes for a [M, Cout] output with reduction length K;
+ * mdm_conv_fwd_ws: mdm_conv_fwd with that workspace (NULL / too small = never split). */
+int mdm_conv_fwd_plan(int M, int Cout, int K, int dtype, int* splits, size_t* ws_bytes);
+int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float* bias, const void* res, const void* aux, void* y,
+                    void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride,
+                    int transposed, int act, int kblock, int dtype, float* ws, size_t ws_bytes, void* stream);
 int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes);
 int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, float* ws, int N, int H, int W, int Cin, int Ho,
                    int Wo, int Cout, int ksize, int stride, int dtype, void* stream);

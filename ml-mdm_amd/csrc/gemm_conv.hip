@@ -44,6 +44,10 @@ struct ConvArgs {
   int act;            // 0 none, 1 y=gelu(v), 2 y=v*gelu'(aux)
   int kblk;           // 3x3 k-order: 0 = tap-major (k = tap*Cin + cin); B = channel-block-major,
                       // k = (cin / B) * 9 * B + tap * B + cin % B with B = the k-tile (64 bf16 / 32 fp32)
+  // split-K launches (conv_gemm_bl_kernel<..., SPLITK>): the reduction is cut into `ksplit` ranges of `kt_per` k-tiles,
+  // range s writes its raw fp32 tile to part[s][M][Cout]; splitk_epilogue_kernel adds them up and applies the epilogue
+  float* part;
+  int ksplit, kt_per;
 };
 
 enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };
@@ -371,11 +375,12 @@ struct ConvGroup {
 };
 struct NoConvGroup {};
 
-template <int BM, int BN, int WM, int WN, int MODE, bool GROUPED = false>
+template <int BM, int BN, int WM, int WN, int MODE, bool GROUPED = false, bool SPLITK = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs p, std::conditional_t<GROUPED, ConvGroup, NoConvGroup> gr) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type has no host-side counterpart: the host pass only needs the stub
   using T = bf16;
   static_assert(!GROUPED || MODE == MODE_1x1, "grouped launches: 1x1 / linear only");
+  static_assert(!(GROUPED && SPLITK), "split-K launches are single problems");
   constexpr int NT_ = WM * WN * 64;
   constexpr int RPP = NT_ / 8;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   // within each group of G the XCD-aware remap keeps neighbouring tiles (shared operand panels) on one XCD's L2.
   const int tiles_n = (p.Cout + BN - 1) / BN;
   const int tiles_per_problem = ((p.M + BM - 1) / BM) * tiles_n;
-  const int tiles_total = tiles_per_problem * (GROUPED ? p.groups : 1);
+  const int tiles_total = tiles_per_problem * (GROUPED ? p.groups : 1) * (SPLITK ? p.ksplit : 1);
   const int G = gridDim.x;
   const int b_in_group = xcd_remap(blockIdx.x, G);
 
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   const unsigned bias = MODE == MODE_3x3 ? (unsigned)(p.W + 1) * p.Cin * 2u : 0u;   // base shift that keeps the per-tap scalar offset non-negative
   unsigned a_voff[AJ], a_mask[AJ], b_voff[BJ];
   int m0 = 0, n0 = 0, grp = 0;
+  int split = 0, kt0 = 0, nloc = p.K / 64;   // SPLITK: this tile's reduction range = k-tiles [kt0, kt0 + nloc)
   char* a_base = const_cast<char*>(reinterpret_cast<const char*>(p.x)) - bias;
   char* b_base = const_cast<char*>(reinterpret_cast<const char*>(p.w));
 #define MDM_TILE_SETUP(tile_)                                                                               \
@@ -414,6 +420,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
       grp = tl_ / tiles_per_problem; tl_ -= grp * tiles_per_problem;                                        \
       a_base = const_cast<char*>(reinterpret_cast<const char*>(gr.x[grp]));                                 \
       b_base = const_cast<char*>(reinterpret_cast<const char*>(gr.w[grp]));                                 \
+    }                                                                                                       \
+    if constexpr (SPLITK) {                                                                                 \
+      split = tl_ / tiles_per_problem; tl_ -= split * tiles_per_problem;                                    \
+      kt0 = split * p.kt_per; nloc = min(p.kt_per, p.K / 64 - kt0);                                         \
     }                                                                                                       \
     m0 = (tl_ / tiles_n) * BM; n0 = (tl_ % tiles_n) * BN;                                                   \
     _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                        \
@@ -453,13 +463,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   // Per-k-tile wave-uniform state of the loader: buffer descriptors (empty past the last tile, so the same loads
   // fetch nothing), the A-side scalar offset (tap shift + channel block) and the tap's bit in the halo masks.
 #define MDM_TILE_STATE(kt_)                                                                                 \
-  const bool more_ = (kt_) < ntiles;                                                                        \
+  const bool more_ = (kt_) < (SPLITK ? nloc : ntiles);                                                      \
+  const int kta_ = SPLITK ? kt0 + (kt_) : (kt_);                                                            \
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc(a_base, 0, more_ ? a_bytes : 0u, 0x00020000);         \
   const auto rsB = __builtin_amdgcn_make_buffer_rsrc(b_base, 0, more_ ? b_bytes : 0u, 0x00020000);         \
-  const int b_soff = (kt_) * 128;                                                                           \
+  const int b_soff = kta_ * 128;                                                                            \
   int a_soff = b_soff, tapbit = 1;                                                                          \
   if (MODE == MODE_3x3) {                                                                                   \
-    const int cb = (kt_) / 9, tap = (kt_) - 9 * cb;                                                         \
+    const int cb = kta_ / 9, tap = kta_ - 9 * cb;                                                           \
     const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;                                                      \
     a_soff = (kh * p.W + kw) * p.Cin * 2 + cb * 128;                                                        \
     tapbit = 1 << tap;                                                                                      \
@@ -511,7 +522,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
 #pragma unroll
     for (int i = 0; i < MT; ++i) load_frag<T>(af[i], smem, wm * TM + i * 16 + l16, 0, quad);
     constexpr int DMA_PER_ROW = (AJ + BJ + MT - 1) / MT;
-    for (int kt = 0; kt < ntiles; ++kt) {
+    const int kt_end = SPLITK ? nloc : ntiles;
+    for (int kt = 0; kt < kt_end; ++kt) {
       const char* As = smem + (kt & 1) * STAGE;
       const char* Bs = As + A_BYTES;
       // ---- phase A
@@ -553,14 +565,33 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
     __syncthreads();   // LDS is reused by the epilogue
     const int cur_m0 = m0, cur_n0 = n0;
     const int next = tile + G;
-    ConvArgs pe = p;   // the epilogue's view of this tile's problem (the prefetch below already moves on to the next)
-    if constexpr (GROUPED) { pe.bias = gr.bias[grp]; pe.y = gr.y[grp]; }
-    conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE>(pe, acc, smem, cur_m0, cur_n0, [&]() {
+    if constexpr (SPLITK) {
+      // raw fp32 tile of this reduction range -> part[split]; the LDS is not needed, so the next tile's DMA starts first
+      float* __restrict__ P = p.part + (size_t)split * p.M * p.Cout;
       if (next < tiles_total) {
         MDM_TILE_SETUP(next);
         MDM_TILE_PROLOGUE();
       }
-    });
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = cur_m0 + wm * TM + i * 16 + l16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = cur_n0 + wn * TN + j * 16 + quad * 4;
+          if (n < p.Cout) *reinterpret_cast<f32x4*>(P + (size_t)m * p.Cout + n) = acc[i][j];   // Cout % 8 == 0 (host-checked)
+        }
+      }
+    } else {
+      ConvArgs pe = p;   // the epilogue's view of this tile's problem (the prefetch below already moves on to the next)
+      if constexpr (GROUPED) { pe.bias = gr.bias[grp]; pe.y = gr.y[grp]; }
+      conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE>(pe, acc, smem, cur_m0, cur_n0, [&]() {
+        if (next < tiles_total) {
+          MDM_TILE_SETUP(next);
+          MDM_TILE_PROLOGUE();
+        }
+      });
+    }
     if (next >= tiles_total) break;
     tile = next;
   }
@@ -1657,6 +1688,42 @@ using namespace mdm;
 // ---------------------------------------------------------------------------
 // name (as rocprofv3 prints it, without the argument list) of the GEMM-class kernel the calling thread launched last:
 // lets bench.py label its per-launch HIP-event timings with the kernel that actually ran
+// ---- split-K second stage: y = epilogue(sum_s part[s] + bias) --------------------------------------------------
+// Same arithmetic as conv_epilogue: the sum (+ bias) is rounded to T first, the activation / pre-activation store /
+// residual add see the rounded value.  One thread per 4 consecutive channels of one output row.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part, int ksplit, size_t mc,
+                                                              int Cout, const float* __restrict__ bias,
+                                                              const T* __restrict__ res, const T* __restrict__ aux,
+                                                              T* __restrict__ y, T* __restrict__ ypre, int act) {
+  const size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (idx >= mc) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(part + idx);
+  for (int sp = 1; sp < ksplit; ++sp) s += *reinterpret_cast<const f32x4*>(part + (size_t)sp * mc + idx);
+  const int n = (int)(idx % (size_t)Cout);
+  if (bias) s += *reinterpret_cast<const f32x4*>(bias + n);
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = to_f32(from_f32<T>(s[e]));
+  if (act == 1) {
+    if (ypre) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ypre[idx + e] = from_f32<T>(v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+  } else if (act == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(to_f32(aux[idx + e]));
+  }
+  if (res) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += to_f32(res[idx + e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y[idx + e] = from_f32<T>(v[e]);
+}
+
 static thread_local char g_last_gemm[96] = "";
 extern "C" const char* mdm_last_gemm_kernel(void) { return g_last_gemm; }
 #define MDM_NOTE_KERNEL(...) snprintf(g_last_gemm, sizeof(g_last_gemm), __VA_ARGS__)
@@ -1706,6 +1773,49 @@ static bool conv_bl_ok(const ConvArgs& a) {
   return 2 * bias + (size_t)a.K * 2 < 0x00F00000u;   // INVALID + any tile offset stays below 2^31
 }
 
+// Split-K for problems that cannot fill the chip with output tiles (sampling at batch 1-4: M = 1024 at the 16x16 level
+// gives 48 tiles of 128x128, each walking all 108 k-tiles of a 3x3 768 -> 768 convolution -- 73 us for 15 us of work).
+// Splits: enough blocks for two per CU, at least 6 k-tiles each, at most 16, and only when the split saves at least 16
+// k-tiles of serial walk (~10 us) -- the second launch costs about that much.  1 = do not split.
+static int conv_ksplit(int M, int Cout, int K, int dtype) {
+  if (dtype != DT_BF16 || K % 64 != 0 || Cout % 8 != 0 || Cout <= 64) return 1;
+  const long tiles = (long)((M + 127) / 128) * ((Cout + 127) / 128);
+  const int nt = K / 64, cus = device_cus();
+  if (tiles * 2 > cus || nt < 12) return 1;
+  long sp = (2L * cus) / tiles;
+  if (sp > nt / 6) sp = nt / 6;
+  if (sp > 16) sp = 16;
+  if (sp < 2 || nt - (nt + sp - 1) / sp < 16) return 1;
+  return (int)sp;
+}
+
+extern "C" int mdm_conv_fwd_plan(int M, int Cout, int K, int dtype, int* splits, size_t* ws_bytes) {
+  MDM_CHECK_ARG(splits && ws_bytes && M > 0 && Cout > 0 && K > 0);
+  *splits = conv_ksplit(M, Cout, K, dtype);
+  *ws_bytes = *splits > 1 ? (size_t)*splits * M * Cout * sizeof(float) : 0;
+  return 0;
+}
+
+template <int MODE>
+static int launch_conv_bl_splitk(ConvArgs a, int splits, float* ws, hipStream_t st) {
+  constexpr int BM = 128, BN = 128, WM = 2, WN = 2;
+  constexpr int smem = 2 * (BM + BN) * 128;
+  auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE, false, true>;
+  ensure_dynamic_lds(kern, smem);
+  const int nt = a.K / 64;
+  a.kt_per = (nt + splits - 1) / splits;
+  a.ksplit = (nt + a.kt_per - 1) / a.kt_per;   // every range non-empty
+  a.part = ws;
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN) * a.ksplit;
+  const int resident = device_cus() * 2;
+  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a, NoConvGroup{});
+  const size_t mc = (size_t)a.M * a.Cout;
+  hipLaunchKernelGGL(splitk_epilogue_kernel<bf16>, dim3((unsigned)((mc / 4 + 255) / 256)), dim3(256), 0, st, ws, a.ksplit, mc,
+                     a.Cout, a.bias, (const bf16*)a.res, (const bf16*)a.aux, (bf16*)a.y, (bf16*)a.ypre, a.act);
+  MDM_NOTE_KERNEL("conv_gemm_bl_kernel<%d, %d, %d, %d, %d, splitk x%d>", BM, BN, WM, WN, MODE, a.ksplit);
+  MDM_LAUNCH_STATUS();
+}
+
 // Block tile (BM * 1000 + BN) of the forward / dgrad kernel for a problem.  bf16: the candidates are 128x128
 // (2 blocks / CU), 256x192 and 256x256 (1 block / CU); the cheapest by rounds x tile area / relative efficiency wins
 // (relative efficiencies measured with tools/kbench.py: the larger tiles move fewer LDS bytes per FLOP; N = 768 --
@@ -1752,10 +1862,12 @@ static int launch_conv_t(const ConvArgs& a, int ks, int transposed, hipStream_t 
   return launch_conv_mode<T, MODE_3x3>(a, st);
 }
 
-extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const void* res,
-                            const void* aux, void* y, void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo,
-                            int Cout, int ksize, int stride, int transposed, int act, int kblock, int dtype,
-                            void* stream) {
+// ws / ws_bytes: optional fp32 workspace sized by mdm_conv_fwd_plan; with it, problems too small to fill the chip with
+// output tiles run split over the reduction (two launches: partial tiles, then sum + epilogue).  NULL = never split.
+extern "C" int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float* bias, const void* res,
+                               const void* aux, void* y, void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo,
+                               int Cout, int ksize, int stride, int transposed, int act, int kblock, int dtype,
+                               float* ws, size_t ws_bytes, void* stream) {
   MDM_CHECK_ARG(x && w_packed && y);
   MDM_CHECK_ARG(ksize == 1 || ksize == 3);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
@@ -1774,9 +1886,26 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
   const int bk = dtype == DT_F32 ? 32 : 64;
   MDM_CHECK_ARG(kblock == 0 || (ksize == 3 && kblock == bk && Cin % bk == 0));
   a.kblk = kblock;
+  a.part = nullptr; a.ksplit = 1; a.kt_per = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (ws && dtype == DT_BF16 && !transposed && stride == 1) {
+    const int sp = conv_ksplit(a.M, Cout, a.K, dtype);
+    if (sp > 1 && ws_bytes >= (size_t)sp * a.M * Cout * sizeof(float)) {
+      if (ksize == 1 && conv_bl_ok<bf16, MODE_1x1>(a)) return launch_conv_bl_splitk<MODE_1x1>(a, sp, ws, st);
+      if (ksize == 3 && conv_bl_ok<bf16, MODE_3x3>(a)) return launch_conv_bl_splitk<MODE_3x3>(a, sp, ws, st);
+    }
+  }
   return dtype == DT_F32 ? launch_conv_t<float>(a, ksize, transposed, st) : launch_conv_t<bf16>(a, ksize, transposed, st);
 }
+
+extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const void* res,
+                            const void* aux, void* y, void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo,
+                            int Cout, int ksize, int stride, int transposed, int act, int kblock, int dtype,
+                            void* stream) {
+  return mdm_conv_fwd_ws(x, w_packed, bias, res, aux, y, y_pre, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, transposed, act,
+                         kblock, dtype, nullptr, 0, stream);
+}
+
 
 // y[g] [M, Cout] = x[g] [M, Cin] * w_packed[g]^T + bias[g] for `groups` (<= 32) linear layers of one shape, bf16, in ONE
 // launch.  The pointer arrays are HOST arrays of device pointers; bias may be NULL (no bias at all) .  Passing the

@@ -497,11 +497,28 @@ def profile_end(peak_tflops, peak_gbs=8000.0):
 # --------------------------------------------------------------------------------------
 # raw launches
 # --------------------------------------------------------------------------------------
+_conv_plans = {}   # (M, Cout, K, dtype) -> (splits, workspace bytes) of mdm_conv_fwd_plan
+
+
+def _conv_plan(M, Cout, K, dt):
+    key = (M, Cout, K, dt)
+    ent = _conv_plans.get(key)
+    if ent is None:
+        sp, wsb = ctypes.c_int(1), ctypes.c_size_t(0)
+        _lib.check(_lib.lib().mdm_conv_fwd_plan(M, Cout, K, dt, ctypes.byref(sp), ctypes.byref(wsb)), "mdm_conv_fwd_plan")
+        ent = _conv_plans[key] = (sp.value, wsb.value)
+    return ent
+
+
 def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, stride, transposed, act, kblk=0):
+    # problems too small to fill the chip with output tiles (sampling at batch 1-4) run split over the reduction
+    splits, wsb = _conv_plan(N * Ho * Wo, Cout, ks * ks * Cin, _dt(x)) if (stride == 1 and not transposed) else (1, 0)
+    ws = _f32_ws(wsb, x.device) if splits > 1 else None
+
     def go():
         _lib.check(
-            _lib.lib().mdm_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(aux), _p(y), _p(ypre), N, H, W, Cin, Ho, Wo, Cout,
-                                    ks, stride, transposed, act, kblk, _dt(x), _stream()),
+            _lib.lib().mdm_conv_fwd_ws(_p(x), _p(w), _p(bias), _p(res), _p(aux), _p(y), _p(ypre), N, H, W, Cin, Ho, Wo, Cout,
+                                       ks, stride, transposed, act, kblk, _dt(x), _p(ws), wsb, _stream()),
             "mdm_conv_fwd",
         )
 

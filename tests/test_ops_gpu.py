@@ -584,3 +584,60 @@ def test_repack_all_matches_single_weight_pack(dtype):
             assert (a is None) == (b is None)
             if a is not None:
                 assert torch.equal(a, b), tuple(w.shape)
+
+
+@pytest.mark.parametrize("case", ["conv3x3_res", "conv1x1_res", "ffn"])
+def test_small_problem_split_k_matches_unsplit(case):
+    """sampling at batch 1: too few output tiles to fill the chip, so the reduction is split over blocks (partial fp32
+    tiles + one sum/epilogue launch).  Same result as the unsplit launch up to the order of the fp32 sum -- forward and
+    every gradient (the FFN backward exercises the x gelu'(aux) epilogue of the second stage) -- and the split path is
+    the one that ran."""
+    from mdm_hip import ops
+    g = torch.Generator().manual_seed(17)
+    N, H = 1, 16
+    if case == "conv3x3_res":
+        C = 768
+        w = (torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(dev()).requires_grad_()
+    elif case == "conv1x1_res":
+        C = 768
+        w = (torch.randn(C, 4 * C, 1, 1, generator=g) / (2 * C ** 0.5)).to(dev()).requires_grad_()
+    else:
+        # wide -> narrow -> wide, so that the LONG reductions are the ones with the GELU epilogues: the up-projection
+        # (GELU + pre-activation store) forward and the x gelu'(aux) input gradient of the down-projection backward
+        C = 3072
+        w = (torch.randn(768, C, 1, 1, generator=g) / C ** 0.5).to(dev()).requires_grad_()
+        w2 = (torch.randn(C, 768, 1, 1, generator=g) / (2 * 768 ** 0.5)).to(dev()).requires_grad_()
+        b2 = (0.1 * torch.randn(C, generator=g)).to(dev()).requires_grad_()
+    b = (0.1 * torch.randn(w.shape[0], generator=g)).to(dev()).requires_grad_()
+    x0 = torch.randn(N, H, H, w.shape[1], generator=g).to(dev()).to(torch.bfloat16)
+    r0 = torch.randn(N, H, H, C, generator=g).to(dev()).to(torch.bfloat16)
+
+    def run():
+        x, r = x0.clone().requires_grad_(), r0.clone().requires_grad_()
+        if case == "ffn":
+            y = ops.ffn(x, w, b, w2, b2, r)
+            ps = (x, r, w, b, w2, b2)
+        else:
+            y = ops.conv(x, w, b, residual=r)
+            ps = (x, r, w, b)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dev()).to(y.dtype)
+        return [y.detach().float()] + [t.float() for t in torch.autograd.grad(y, ps, gy)]
+
+    real_plan = ops._conv_plan
+    seen = []
+
+    def spy(M, Cout, K, dt):
+        sp = real_plan(M, Cout, K, dt)
+        seen.append(sp[0])
+        return sp
+
+    ops._conv_plan = spy
+    try:
+        split = run()
+        ops._conv_plan = lambda M, Cout, K, dt: (1, 0)
+        plain = run()
+    finally:
+        ops._conv_plan = real_plan
+    assert sum(1 for v in seen if v > 1) >= (2 if case == "ffn" else 1), seen   # the launches this case is about were split
+    for a, b_ in zip(split, plain):
+        assert relerr(a, b_) < 8e-3     # bf16 outputs: an fp32 sum in another order moves a few results by one ulp (2^-8)
