@@ -69,6 +69,32 @@ def test_tile_and_split_cost_models():
     assert L.mdm_conv_wgrad_tile(16384, 768, 3072, F32) == 128
 
 
+def test_forward_split_k_plan():
+    """host-side planning of the small-problem split (mdm_conv_fwd_plan; 256 CUs assumed without a GPU): training shapes
+    never split; sampling shapes at batch 1-4 do, with >= 6 k-tiles per range, <= 16 ranges, and only when the cut
+    saves >= 16 k-tiles of serial walk"""
+    from mdm_hip import _lib
+
+    L = _lib.lib()
+    BF16, F32 = 1, 0
+
+    def plan(M, Cout, K, dt=BF16):
+        sp, ws = ctypes.c_int(0), ctypes.c_size_t(0)
+        assert L.mdm_conv_fwd_plan(M, Cout, K, dt, ctypes.byref(sp), ctypes.byref(ws)) == 0
+        assert ws.value == (sp.value * M * Cout * 4 if sp.value > 1 else 0)
+        return sp.value
+
+    for (M, Cout, K) in [(16384, 768, 6912), (65536, 512, 4608), (262144, 256, 2304), (16384, 3072, 768), (16384, 768, 3072)]:
+        assert plan(M, Cout, K) == 1, (M, Cout, K)            # batch 64: the output tiles fill the chip
+    for (M, Cout, K) in [(1024, 768, 6912), (1024, 768, 13824), (4096, 512, 4608), (1024, 768, 3072), (256, 768, 6912)]:
+        sp = plan(M, Cout, K)
+        nt = K // 64
+        assert 2 <= sp <= 16 and nt // sp >= 6 and nt - -(-nt // sp) >= 16, (M, Cout, K, sp)
+    assert plan(1024, 768, 768) == 1                            # 12 k-tiles: a second launch costs more than it saves
+    assert plan(1024, 3072, 768) == 1                           # 192 tiles already give most CUs a block
+    assert plan(1024, 768, 6912, F32) == 1 and plan(1024, 64, 6912) == 1 and plan(1024, 768, 6900) == 1
+
+
 def test_invalid_arguments_rejected_before_launch():
     from mdm_hip import _lib
 
