@@ -98,6 +98,27 @@ def main():
             fl = 2.0 * G * M * cin * cout
             t1 = timeit(lambda: [ops._wgrad_launch(xs[i].view(B, H, H, cin), dys[i].view(B, H, H, cout), B, H, H, cin, H, H, cout, 1, 1, out=dws[i], dbias=dbs[i]) for i in range(G)], iters=3)
             print("%-22s grouped x%d %7.3f ms %7.1f TF   one-by-one (split + reduce) %7.3f ms %7.1f TF" % (name, G, t * 1e3, fl / t / 1e12, t1 * 1e3, fl / t1 / 1e12), flush=True)
+    if what in ("adamw",):
+        # the fused optimizer pass on a UNet-64-sized arena (415 M parameters): 5 reads + 5 writes of 4 bytes each
+        n = 415_000_000
+        p_, g_, m_, v_, e_ = [torch.zeros(n, device=dev) for _ in range(5)]
+        g_.normal_()
+        gn = torch.ones(1, device=dev)
+        def step():
+            ops.adamw_ema_step(p_, g_, m_, v_, e_, gn, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1, 2.0, 0.9999, zero_grad=True)
+        for _ in range(2):
+            step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 10e3
+        print("adamw_ema %d M parameters: %.3f ms  %.0f GB/s" % (n // 1000000, t * 1e3, 40.0 * n / t / 1e9), flush=True)
+        ws_ = torch.empty(1)
+        t = timeit(lambda: ops.sumsq(g_))
+        print("sumsq: %.3f ms  %.0f GB/s" % (t * 1e3, 4.0 * n / t / 1e9), flush=True)
     if what in ("pack",):
         # the optimizer tail's re-pack of every kernel-layout weight (ops.repack_all) on a UNet-64-like weight set
         shapes = [((256, 256, 3, 3), 7), ((512, 512, 3, 3), 6), ((768, 768, 3, 3), 10), ((256, 512, 3, 3), 3), ((512, 768, 3, 3), 1),
