@@ -125,10 +125,12 @@ class Diffusion(nn.Module):
             inv = 1.0 / sc.rescale_signal if sc.rescale_signal else 1.0
             x_t, eps = ops.noise_images(images.float(), g, eps.float(), inv_scale=inv)
             means, _ = self.model(x_t, time, lm_outputs, lm_mask, self.get_micro_conditioning(sample))
-            loss = ops.diffusion_loss(means, x_t, images.float(), eps, g, sc.prediction_type, sc.loss_target_type, inv_scale=inv)
+            # the reference builds x_t from the RESCALED images but the target from the raw ones (diffusion.py:153, 163):
+            # the target term of the loss kernel gets scale 1 (they differ only for a V-prediction target with rescale_signal)
+            loss = ops.diffusion_loss(means, x_t, images.float(), eps, g, sc.prediction_type, sc.loss_target_type, inv_scale=1.0)
             tgt = None
             if self.materialize_targets:
-                tgt = self.sampler.get_prediction_targets(self.sampler.get_image_rescaled(images), eps, g, g_last, sc.loss_target_type)
+                tgt = self.sampler.get_prediction_targets(images, eps, g, g_last, sc.loss_target_type)
             return loss, time, x_t, means, tgt, weights
         x_t = self.sampler.get_xt(self.sampler.get_image_rescaled(images), eps, g)
         means, _ = self.model(x_t, time, lm_outputs, lm_mask, self.get_micro_conditioning(sample))

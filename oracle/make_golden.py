@@ -42,7 +42,8 @@ def main():
     R = ref_import.load()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
-    for name in PC.CASES:
+    only = [a for a in sys.argv[2:] if a in PC.ALL_CASES]
+    for name in (only or PC.ALL_CASES):
         _, cfg, sd = PC.build_module(name)
         rcfg = to_ref_cfg(R, cfg)
         cls = R.nested_unet.NestedUNet if hasattr(rcfg, "inner_config") else R.unet.UNet
@@ -50,7 +51,7 @@ def main():
         missing, unexpected = ref.load_state_dict(sd, strict=True)
         assert not missing and not unexpected
         inp = PC.inputs(name)
-        outs = ref(inp["x"], inp["times"], inp["cond"], inp["mask"])
+        outs = ref(inp["x"], inp["times"], inp["cond"], inp["mask"], inp["micros"])
         PC.loss_of(outs, inp["gys"]).backward()
         grads = {k: p.grad for k, p in ref.named_parameters()}
         assert all(g is not None for g in grads.values())
@@ -102,6 +103,13 @@ def diffusion_host_golden():
     pipe_v = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=sc(), use_vdm_loss_weights=True))
     torch.manual_seed(11)
     blob["loss_vdm_weights"] = pipe_v.get_loss(sample)[5].detach()
+    # round 3 (ADVICE): rescale_signal = 2 with a V-prediction TARGET -- x_t is built from the rescaled images, the
+    # target from the raw ones (diffusion.py:153, 163)
+    pipe_r = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(
+        sampler_config=sc(rescale_signal=2, loss_target_type=S.PredictionType.V_PREDICTION), use_vdm_loss_weights=False))
+    torch.manual_seed(11)
+    loss, time, x_t, means, tgt, w = pipe_r.get_loss(sample)
+    blob["loss_rescale2_vtarget"] = dict(loss=loss.detach(), x_t=x_t.detach(), tgt=tgt.detach())
     for tag, kw in (("ddim", dict(ddim_eta=0)), ("ddpm", dict()), ("ddim_cfg", dict(ddim_eta=0, guidance_scale=3.0)),
                     ("ddpm_eta1_dyn", dict(ddim_eta=1))):
         cfg = sc(threshold_function=S.ThresholdType.DYNAMIC) if tag.endswith("dyn") else sc()
@@ -122,6 +130,13 @@ def diffusion_host_golden():
     torch.manual_seed(17)
     loss, time, x_t, pred, tgt, w = npipe.get_loss(nsample)
     blob["nested_loss"] = dict(loss=loss.detach(), time=time, x_t=x_t.detach(), pred=pred.detach(), tgt=tgt.detach())
+    # round 3: mixed_ratio '2:1' (cc12m_256x256.yaml:108; diffusion.py:258-275, 374-381)
+    mcfg = D.NestedDiffusionConfig(sampler_config=sc(schedule_shifted=True, rescale_signal=1), use_vdm_loss_weights=False,
+                                   use_double_loss=True, no_use_residual=True, mixed_ratio="2:1")
+    mpipe = D.NestedDiffusion(SM.StubNestedUNet(), mcfg)
+    torch.manual_seed(17)
+    loss, time, x_t, pred, tgt, w = mpipe.get_loss(nsample)
+    blob["nested_loss_mixed"] = dict(loss=loss.detach(), x_t=x_t.detach(), pred=pred.detach(), tgt=tgt.detach())
     torch.manual_seed(19)
     with torch.no_grad():
         out = npipe.sample(3, nsample, 32, torch.device("cpu"), resample_steps=True, num_inference_steps=4, ddim_eta=0)
@@ -169,6 +184,24 @@ def sampling_golden():
         loss = pipe.get_loss(smp)[0]
         blob[name] = {"sample": img.detach().clone(), "loss": loss.detach().clone()}
         print(name, "sample", tuple(img.shape), "loss", loss.tolist())
+        if nested:
+            # round 3: the shipped yaml key ``mixed_ratio: '2:1'`` (cc12m_256x256.yaml:108): the 32x32 level sees the first
+            # int(2/3 * B) samples only, its loss is divided by 2/3 and zeroed for the rest (diffusion.py:258-275, 374-381);
+            # B = 3 -> bh = 2, bl = 3.  Explicit micro-conditioning rides along (diffusion.py:136-141).
+            mp = D.NestedDiffusion(ref, D.NestedDiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False,
+                                                                use_double_loss=True, no_use_residual=True, mixed_ratio="2:1"))
+            minp = PC.inputs("mini_nested_mixed")
+            g = torch.Generator().manual_seed(37)
+            msmp = {"lm_outputs": minp["cond"], "lm_mask": minp["mask"], "scale": minp["micros"]["scale"],
+                    "images": torch.rand(3, 3, side, side, generator=g) * 2 - 1}
+            torch.manual_seed(41)
+            mp.train()
+            mloss = mp.get_loss(msmp)[0]
+            mloss.sum().backward()
+            blob["mini_nested_mixed"] = {"loss": mloss.detach().clone(),
+                                         "grad_norm": {k: float(p.grad.double().norm()) for k, p in ref.named_parameters()}}
+            ref.zero_grad(set_to_none=True)
+            print("mini_nested mixed_ratio 2:1 loss", mloss.tolist())
     path = os.path.join(ROOT, "tests", "golden", "pipeline.pt")
     torch.save(blob, path)
     print("wrote", path, os.path.getsize(path), "bytes")

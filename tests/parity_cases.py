@@ -11,9 +11,18 @@ import torch
 import unet_oracle as O
 
 
+def _base(name):
+    """architecture of a case: the *_micros / *_mixed variants reuse a base architecture with other inputs"""
+    for suf in ("_micros", "_mixed"):
+        if name.endswith(suf):
+            return name[: -len(suf)]
+    return name
+
+
 def _cfg(name):
     from mdm_hip import configs
 
+    name = _base(name)
     return {
         "mini_unet": configs.mini_unet_config,
         "mini_unet_masked": lambda: configs.mini_unet_config(masked=1),
@@ -25,7 +34,16 @@ def _cfg(name):
 # mini_nested2: three nesting levels (64 + 32 + 16) whose middle net normalises its input by the per-sample std
 # (skip_normalization=False) -- the topology of the reference's cc12m_1024x1024.yaml at test size
 CASES = ["mini_unet", "mini_unet_masked", "mini_nested", "mini_nested2"]
+# round 3: inputs the reference's call surface accepts and the first four cases never passed
+#   *_micros  explicit micro-conditioning ``micros={"scale": ...}`` with values below AND above the net's default, i.e.
+#             both sides of the clamp (models/unet.py:920-933)
+#   *_mixed   mixed-resolution batches: the higher resolutions run on a prefix of the batch only (bh < bl; the
+#             ``mixed_ratio`` slicing of diffusion.py:258-275 as the vision model sees it, nested_unet.py:186-212),
+#             with explicit micros as well
+EXTRA_CASES = ["mini_unet_micros", "mini_nested_mixed", "mini_nested2_mixed"]
+ALL_CASES = CASES + EXTRA_CASES
 _SIDES = {"mini_unet": [16], "mini_unet_masked": [16], "mini_nested": [32, 16], "mini_nested2": [64, 32, 16]}
+_MIXED_BATCH = {"mini_nested_mixed": [2, 3], "mini_nested2_mixed": [1, 2, 3]}   # samples per resolution, high -> low
 
 
 def build_module(name, seed=0):
@@ -43,19 +61,26 @@ def build_module(name, seed=0):
 
 def inputs(name, seed=1):
     g = torch.Generator().manual_seed(seed)
-    B, S, D = 2, 8, 64
+    per_level = _MIXED_BATCH.get(name)
+    B, S, D = (per_level[-1] if per_level else 2), 8, 64
     cond = torch.randn(B, S, D, generator=g)
     mask = torch.ones(B, S)
     mask[1, 5:] = 0
     cond = cond * mask.unsqueeze(-1)
-    times = torch.tensor([3, 977])
-    sides = _SIDES[name]
-    xs = [torch.randn(B, 3, sd, sd, generator=g) for sd in sides]
-    if name == "mini_nested2":
+    times = torch.tensor([3, 977, 420][:B])
+    sides = _SIDES[_base(name)]
+    per_level = per_level or [B] * len(sides)
+    xs = [torch.randn(b, 3, sd, sd, generator=g) for sd, b in zip(sides, per_level)]
+    if _base(name) == "mini_nested2":
         xs[1] = xs[1] * 1.7 + 0.3   # make the std-normalisation of the middle level visible (std != 1, mean != 0)
     x = xs if len(sides) > 1 else xs[0]
-    gys = [torch.randn(B, 3, sd, sd, generator=g) for sd in sides]
-    return dict(x=x, times=times, cond=cond, mask=mask, gys=gys)
+    gys = [torch.randn(b, 3, sd, sd, generator=g) for sd, b in zip(sides, per_level)]
+    micros = {}
+    if name != _base(name):
+        # every net of a nest clamps against ITS OWN default (16 / 32 / 64 for the mini nets): 7 is below all of them,
+        # 40 between, 100 above all
+        micros = {"scale": torch.tensor([7.0, 40.0, 100.0][:B])}
+    return dict(x=x, times=times, cond=cond, mask=mask, gys=gys, micros=micros)
 
 
 def probe_for(key, shape):
@@ -85,7 +110,7 @@ def oracle_run(name, dtype=torch.float32, with_grad=True):
     inp = inputs(name)
     leaf = {k: v.to(dtype).clone().requires_grad_(with_grad) for k, v in sd.items()}
     cast = lambda t: [u.to(dtype) for u in t] if isinstance(t, list) else t.to(dtype)
-    outs = O.model_forward(leaf, cfg, cast(inp["x"]), inp["times"], inp["cond"].to(dtype), inp["mask"].to(dtype))
+    outs = O.model_forward(leaf, cfg, cast(inp["x"]), inp["times"], inp["cond"].to(dtype), inp["mask"].to(dtype), inp["micros"])
     grads = None
     if with_grad:
         loss_of(outs, inp["gys"]).backward()

@@ -12,8 +12,9 @@ class StubUNet(nn.Module):
         self.w = nn.Parameter(torch.tensor(0.35))
 
     def forward(self, x_t, times, lm_outputs, lm_mask, micros={}):
-        t = (times.float() / 1000.0).reshape(-1, 1, 1, 1)
-        c = lm_outputs.mean(dim=(1, 2)).reshape(-1, 1, 1, 1)
+        n = x_t.shape[0]   # mixed-resolution batches: a level may see a prefix of the batch only
+        t = (times[:n].float() / 1000.0).reshape(-1, 1, 1, 1)
+        c = lm_outputs[:n].mean(dim=(1, 2)).reshape(-1, 1, 1, 1)
         return self.w * x_t + 0.1 * torch.tanh(3 * t) + 0.05 * c + 0.02 * torch.roll(x_t, 1, dims=-1)
 
 

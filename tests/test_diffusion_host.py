@@ -54,6 +54,39 @@ def test_get_loss_matches_reference():
     assert torch.allclose(pipe_v.get_loss(sample)[5], GOLD["loss_vdm_weights"])
 
 
+def test_get_loss_rescaled_signal_with_v_target_matches_reference():
+    """rescale_signal = 2 and a V-prediction loss target: x_t from the rescaled images, target from the raw ones
+    (reference diffusion.py:153, 163)"""
+    from mdm_hip import diffusion as D
+
+    sample, _ = batch()
+    pipe = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=sc(rescale_signal=2, loss_target_type="V_PREDICTION"),
+                                                        use_vdm_loss_weights=False))
+    torch.manual_seed(11)
+    loss, time, x_t, means, tgt, w = pipe.get_loss(sample)
+    g = GOLD["loss_rescale2_vtarget"]
+    for a, b in ((loss, g["loss"]), (x_t, g["x_t"]), (tgt, g["tgt"])):
+        assert O.rel_l2(a, b) < 1e-6
+
+
+def test_nested_mixed_ratio_loss_matches_reference():
+    """mixed_ratio '2:1' (cc12m_256x256.yaml:108): the high resolution runs on int(2/3 B) samples, its loss is divided
+    by 2/3 and zeroed for the rest (reference diffusion.py:258-275, 374-381)"""
+    from mdm_hip import diffusion as D
+
+    sample, g = batch()
+    mcfg = D.NestedDiffusionConfig(sampler_config=sc(schedule_shifted=True, rescale_signal=1), use_vdm_loss_weights=False,
+                                   use_double_loss=True, no_use_residual=True, mixed_ratio="2:1")
+    pipe = D.NestedDiffusion(SM.StubNestedUNet(), mcfg)
+    nsample = dict(sample, images=torch.rand(3, 3, 32, 32, generator=g) * 2 - 1)
+    torch.manual_seed(17)
+    loss, time, x_t, pred, tgt, w = pipe.get_loss(nsample)
+    gl = GOLD["nested_loss_mixed"]
+    for a, b in ((loss, gl["loss"]), (x_t, gl["x_t"]), (pred, gl["pred"]), (tgt, gl["tgt"])):
+        assert O.rel_l2(a, b) < 1e-6
+    assert float(loss[2]) > 0   # sample 2 keeps its low-resolution loss only
+
+
 @pytest.mark.parametrize("tag,kw", [("ddim", dict(ddim_eta=0)), ("ddpm", dict()),
                                     ("ddim_cfg", dict(ddim_eta=0, guidance_scale=3.0)),
                                     ("ddpm_eta1_dyn", dict(ddim_eta=1))])

@@ -176,9 +176,13 @@ def test_gpu_get_loss_equals_cpu_formulation():
     from mdm_hip import samplers as S
 
     g = torch.Generator().manual_seed(7)
-    for nested in (False, True):
+    # third variant (round 3, ADVICE): rescale_signal = 2 with a V-prediction target, where x_t uses the rescaled
+    # images and the target the raw ones (reference diffusion.py:153, 163) -- the CPU branch is pinned to the real
+    # reference by tests/test_diffusion_host.py::test_get_loss_rescaled_signal_with_v_target_matches_reference
+    for nested, rescale, target, mixed in ((False, None, "DDPM", None), (True, 1, "DDPM", None), (False, 2, "V_PREDICTION", None),
+                                           (True, 1, "DDPM", "2:1")):
         sc = S.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
-                             loss_target_type="DDPM", schedule_shifted=nested, rescale_signal=1 if nested else None)
+                             loss_target_type=target, schedule_shifted=nested, rescale_signal=rescale)
         side = 32 if nested else 16
         smp = {"images": torch.rand(3, 3, side, side, generator=g) * 2 - 1, "lm_outputs": torch.randn(3, 5, 8, generator=g),
                "lm_mask": torch.ones(3, 5)}
@@ -186,7 +190,8 @@ def test_gpu_get_loss_equals_cpu_formulation():
         for dev in ("cpu", DEV):
             if nested:
                 pipe = D.NestedDiffusion(SM.StubNestedUNet(), D.NestedDiffusionConfig(
-                    sampler_config=sc, use_vdm_loss_weights=False, use_double_loss=True, no_use_residual=True, multi_res_weights="4:1"))
+                    sampler_config=sc, use_vdm_loss_weights=False, use_double_loss=True, no_use_residual=True, multi_res_weights="4:1",
+                    mixed_ratio=mixed))
             else:
                 pipe = D.Diffusion(SM.StubUNet(), D.DiffusionConfig(sampler_config=sc, use_vdm_loss_weights=False))
             pipe = pipe.to(torch.device(dev))

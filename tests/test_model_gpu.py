@@ -27,8 +27,9 @@ def hip_run(name, dtype, with_grad=True):
     inp = PC.inputs(name)
     x = [t.cuda() for t in inp["x"]] if isinstance(inp["x"], list) else inp["x"].cuda()
     ctx = torch.autocast("cuda", dtype=torch.bfloat16) if dtype == torch.bfloat16 else torch.autocast("cuda", enabled=False)
+    micros = {k: v.cuda() for k, v in inp["micros"].items()}
     with ctx:
-        outs = model(x, inp["times"].cuda(), inp["cond"].cuda(), inp["mask"].cuda())
+        outs = model(x, inp["times"].cuda(), inp["cond"].cuda(), inp["mask"].cuda(), micros)
     grads = None
     if with_grad:
         PC.loss_of(outs, inp["gys"]).backward()
@@ -37,8 +38,10 @@ def hip_run(name, dtype, with_grad=True):
     return [o.detach().float().cpu() for o in PC.as_list(outs)], grads
 
 
-@pytest.mark.parametrize("name", PC.CASES)
+@pytest.mark.parametrize("name", PC.ALL_CASES)
 def test_fp32_matches_oracle_and_golden(name):
+    """incl. (round 3) explicit micro-conditioning on both sides of the clamp (models/unet.py:920-933) and
+    mixed-resolution batches bh < bl (models/nested_unet.py:186-212), two and three nesting levels"""
     outs, grads = hip_run(name, torch.float32)
     o_ref, g_ref = PC.oracle_run(name)
     gold = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
@@ -134,6 +137,38 @@ def test_four_step_sampling_and_loss_match_reference_pipeline(name):
     pipe.train()
     loss = pipe.get_loss(smp, time=time.cuda(), noise_fn=lambda like: next(it).to(like.device))[0]
     assert O.rel_l2(loss.float().cpu(), gold["loss"]) < 1e-3
+
+
+def test_mixed_ratio_train_loss_matches_reference_pipeline():
+    """NestedDiffusion.get_loss with the shipped yaml key ``mixed_ratio: '2:1'`` (cc12m_256x256.yaml:108) and explicit
+    micro-conditioning, B = 3 (the 32x32 level runs on 2 samples, the 16x16 level on 3): per-sample losses and every
+    parameter-gradient norm vs what the REAL reference pipeline + reference NestedUNet produced on CPU
+    (tests/golden/pipeline.pt; reference diffusion.py:258-275, 374-381, models/nested_unet.py:186-212)."""
+    from mdm_hip import diffusion as D
+    from mdm_hip import samplers as S
+
+    gold = torch.load(os.path.join(GOLD, "pipeline.pt"), weights_only=False)["mini_nested_mixed"]
+    model, _, _ = PC.build_module("mini_nested")
+    scfg = S.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
+                           loss_target_type="DDPM", threshold_function="CLIP", schedule_shifted=True, rescale_signal=1)
+    pipe = D.NestedDiffusion(model, D.NestedDiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False, use_double_loss=True,
+                                                            no_use_residual=True, mixed_ratio="2:1")).to(torch.device("cuda:0"))
+    inp = PC.inputs("mini_nested_mixed")
+    g = torch.Generator().manual_seed(37)
+    smp = {"lm_outputs": inp["cond"].cuda(), "lm_mask": inp["mask"].cuda(), "scale": inp["micros"]["scale"].cuda(),
+           "images": (torch.rand(3, 3, 32, 32, generator=g) * 2 - 1).cuda()}
+    torch.manual_seed(41)   # replay the reference's CPU draws: timesteps, eps, then one normal_() per lower resolution
+    time = torch.randint(0, 1000, (3,))
+    it = iter([torch.randn(3, 3, 32, 32), torch.randn(3, 3, 16, 16)])
+    pipe.train()
+    loss = pipe.get_loss(smp, time=time.cuda(), noise_fn=lambda like: next(it).to(like.device))[0]
+    assert O.rel_l2(loss.float().cpu(), gold["loss"]) < 1e-4
+    loss.sum().backward()
+    norms = sorted(gold["grad_norm"].values())
+    floor = 1e-2 * norms[len(norms) // 2]
+    for k, p in model.named_parameters():
+        n = gold["grad_norm"][k]
+        assert abs(float(p.grad.double().norm()) - n) <= 1e-3 * max(n, floor), k
 
 
 def test_fused_train_step_matches_torch_optimizer():

@@ -15,7 +15,7 @@ import unet_oracle as O
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("name", PC.CASES)
+@pytest.mark.parametrize("name", PC.ALL_CASES)
 def test_oracle_matches_golden(name):
     gold = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     _, _, sd = PC.build_module(name)
@@ -71,7 +71,7 @@ def test_oracle_matches_full_size_golden(name):
 
 
 @pytest.mark.reference
-@pytest.mark.parametrize("name", ["mini_unet", "mini_nested", "mini_nested2"])
+@pytest.mark.parametrize("name", ["mini_unet", "mini_nested", "mini_nested2"] + PC.EXTRA_CASES)
 def test_oracle_matches_live_reference(name):
     import dataclasses
 
@@ -95,7 +95,7 @@ def test_oracle_matches_live_reference(name):
     ref.load_state_dict(sd, strict=True)
     inp = PC.inputs(name)
     with torch.no_grad():
-        yr = PC.as_list(ref(inp["x"], inp["times"], inp["cond"], inp["mask"]))
+        yr = PC.as_list(ref(inp["x"], inp["times"], inp["cond"], inp["mask"], inp["micros"]))
     yo, _ = PC.oracle_run(name, with_grad=False)
     for a, b in zip(yo, yr):
         assert O.rel_l2(a, b) < 1e-6
