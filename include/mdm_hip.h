@@ -25,6 +25,12 @@
 #define MDM_HIP_H_
 #include <stddef.h>
 
+/* Bumped whenever an exported signature changes; mdm_abi_version() returns the value the library was built with.
+ *   1  round 1
+ *   2  mdm_sumsq / mdm_adamw_ema_step gained parameters, mdm_gn_bwd a third accumulate mode (round 2)
+ *   3  round 3 */
+#define MDM_HIP_ABI_VERSION 3
+
 #ifdef __cplusplus
 extern "C" {
 #endif

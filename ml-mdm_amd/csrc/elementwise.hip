@@ -6,6 +6,7 @@
 // (unet.py:854-861) and dtype casts.  All use 16-byte accesses where the layout
 // allows; everything computes in fp32.
 #include "common.hpp"
+#include "../../include/mdm_hip.h"
 
 namespace mdm {
 
@@ -283,4 +284,4 @@ extern "C" void mdm_set_error(const char* file, int line, const char* what) {
   snprintf(g_err, sizeof(g_err), "%s:%d: %s", base ? base + 1 : file, line, what);
 }
 extern "C" const char* mdm_last_error(void) { return g_err; }
-extern "C" int mdm_abi_version(void) { return 1; }
+extern "C" int mdm_abi_version(void) { return MDM_HIP_ABI_VERSION; }

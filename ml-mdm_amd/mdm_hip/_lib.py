@@ -18,6 +18,8 @@ DEV_HEADER = os.path.join(_ROOT, "include", "mdm_hip_dev.h")    # profiling aids
 LIB_PATH = os.path.join(_HERE, "libmdm_hip.so")
 SOURCES = ["gemm_conv.hip", "norm.hip", "attention.hip", "elementwise.hip", "optim.hip", "diffusion_ops.hip"]
 
+ABI_VERSION = int(re.search(r"#define\s+MDM_HIP_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+
 _lock = threading.Lock()
 _lib = None
 
@@ -29,7 +31,7 @@ class MdmHipError(RuntimeError):
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source for gfx950 into ml-mdm_amd/mdm_hip/libmdm_hip.so (in-tree)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "common.hpp")]
+    deps = srcs + [HEADER, os.path.join(CSRC, "common.hpp")]
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
             return LIB_PATH
@@ -41,7 +43,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
-        if (not force) and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in (s, deps[-1])):
+        if (not force) and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in (s, HEADER, deps[-1])):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
         if verbose:
@@ -116,6 +118,9 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the header and the library drift
             fn.restype = restype
             fn.argtypes = argtypes
+        if handle.mdm_abi_version() != ABI_VERSION:
+            raise MdmHipError("libmdm_hip.so was built for ABI %d, include/mdm_hip.h declares %d: rebuild (__graft_entry__.build())"
+                              % (handle.mdm_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

@@ -65,10 +65,20 @@ def init_distributed_singlenode(timeout: int = 0, backend: str = None):
 
 
 class GradReducer:
-    def __init__(self, params, bucket_mb: float = 256.0, wire_dtype: torch.dtype = None, group=None, tail_mb: float = 8.0):
+    """``world_override=1`` keeps the reducer local whatever ``torch.distributed`` holds (an unwrapped model trains on its
+    own rank's gradients, like the reference without DDP).  ``force_collectives=True`` issues the bucket all-reduces even
+    in a world of one -- the RCCL code path (async all-reduce on arena views, stream ordering, bf16 wire copy-back) can
+    then be exercised on a single GPU (``bench.py --force-collectives``)."""
+
+    def __init__(self, params, bucket_mb: float = 256.0, wire_dtype: torch.dtype = None, group=None, tail_mb: float = 8.0,
+                 world_override: int = None, force_collectives: bool = False):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.nranks = dist.get_world_size(group) if dist.is_initialized() else 1   # divisor of the average
+        if world_override is not None:
+            self.nranks = int(world_override)
+        # ``world`` > 1 switches the hooks / buckets / collectives on (a forced single-rank run pretends 2)
+        self.world = self.nranks if not (force_collectives and self.nranks == 1 and dist.is_initialized()) else 2
         self.wire_dtype = wire_dtype
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
@@ -171,11 +181,11 @@ class GradReducer:
         buf = self.flat[s:e]
         if self.wire_dtype is not None and self.wire_dtype != torch.float32:
             wire = buf.to(self.wire_dtype)
-            wire.div_(self.world)
+            wire.div_(self.nranks)
             h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._work.append((h, buf, wire))
         else:
-            buf.div_(self.world)  # pre-scale: SUM of pre-divided == AVG, and gloo has no AVG
+            buf.div_(self.nranks)  # pre-scale: SUM of pre-divided == AVG, and gloo has no AVG
             h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._work.append((h, None, None))
 
@@ -227,7 +237,7 @@ class GradReducer:
 
     def broadcast_parameters(self, src: int = 0):
         """rank-0 parameters to everyone, as one flat message per 256 MiB (DDP does this at wrap time)"""
-        if self.world == 1:
+        if self.nranks == 1:
             return
         with torch.no_grad():
             chunk, acc = [], 0
@@ -247,3 +257,26 @@ class GradReducer:
         for p in ps:
             p.copy_(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+
+
+class DataParallel(torch.nn.Module):
+    """Drop-in for ``nn.parallel.DistributedDataParallel(diffusion_model.model, device_ids=[local_rank])``
+    (reference clis/train_parallel.py:147-154) that keeps the fused train step: same ``.module`` attribute, same
+    ``no_sync()`` context manager (train_parallel.py:201-203), same call-through ``forward``; the gradient exchange is
+    a ``GradReducer`` over the vision model's parameters (flat arena, large buckets, tail bucket) instead of DDP's
+    25 MiB bucket copies, and rank 0's parameters are broadcast at wrap time like DDP does."""
+
+    def __init__(self, module, device_ids=None, bucket_mb: float = 256.0, wire_dtype: torch.dtype = None, tail_mb: float = 8.0,
+                 force_collectives: bool = False, **unused):
+        super().__init__()
+        self.module = module
+        net = getattr(module, "vision_model", module)
+        self.reducer = GradReducer(list(net.parameters()), bucket_mb=bucket_mb, wire_dtype=wire_dtype, tail_mb=tail_mb,
+                                   force_collectives=force_collectives)
+        self.reducer.broadcast_parameters(0)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def no_sync(self):
+        return self.reducer.no_sync()

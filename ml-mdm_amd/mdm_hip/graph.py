@@ -115,7 +115,7 @@ class GraphedSampler:
         mk = lambda a, dt: torch.as_tensor(a.copy()).to(device=device, dtype=dt)
         return mk(t, torch.long), mk(s, torch.long), mk(gate.astype("float32"), torch.float32)
 
-    def _build(self, key, xs, cond, mask, n_steps, ddim_eta, guidance):
+    def _build(self, key, xs, cond, mask, n_steps, ddim_eta, guidance, micros):
         smp, cfg = self.sampler, self.sampler._config
         model = self.pipe.get_model()
         vm = model.vision_model
@@ -127,6 +127,7 @@ class GraphedSampler:
         idx = torch.zeros(1, dtype=torch.long, device=dev)
         rng = ops.DeviceRng(self._seed, dev)
         x_static = [x.clone() for x in xs]
+        micros_s = {k: v.clone() for k, v in micros.items()}   # micro-conditioning ([B] per key, diffusion.py:136-141): static inputs
         # the text path (lm_proj, masked mean, cond_emb) does not depend on t: computed once per sample() call into
         # static buffers, outside the per-step graph
         ce, cs, cm = vm.forward_conditioning(cond, mask)
@@ -155,7 +156,7 @@ class GraphedSampler:
                 tin = torch.cat([times, times])
             else:
                 xin, tin = x_static, times
-            preds = vm.forward_denoising(xin if nested else xin[0], tin, ce_s, cs_s, cm_s, {})
+            preds = vm.forward_denoising(xin if nested else xin[0], tin, ce_s, cs_s, cm_s, micros_s)
             preds = list(preds) if nested else [preds]
             if out_scale != 0:
                 preds = [torch.tanh(p / out_scale) * out_scale for p in preds]
@@ -181,7 +182,12 @@ class GraphedSampler:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):   # warm-up: packs weights, sets kernel attributes, sizes the allocator
             for _ in range(self._warmup):
+                idx.zero_()           # every warm-up pass runs step 0 (a 1-step schedule has no step 1 to index)
                 body()
+            # ... and leaves no trace: the first replay starts at step 0 with the generator at (seed, 0), like the
+            # eager sampler after use_device_rng(seed)
+            idx.zero_()
+            rng.state.copy_(torch.tensor([self._seed & (2**63 - 1), 0], dtype=torch.int64))
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -189,7 +195,7 @@ class GraphedSampler:
         # everything the graph reads by raw pointer must outlive it: the schedule tables too (they are locals of this
         # function; once freed, a later allocation reuses their memory and the replayed index_select reads garbage
         # indices -> out-of-bounds gather)
-        ent = dict(graph=graph, x=x_static, ce=ce_s, cs=cs_s, cm=cm_s, idx=idx, rng=rng, n=n_steps,
+        ent = dict(graph=graph, x=x_static, ce=ce_s, cs=cs_s, cm=cm_s, idx=idx, rng=rng, n=n_steps, micros=micros_s,
                    keep=(tab_t, tab_s, tab_gate))
         self._graphs[key] = ent
         return ent
@@ -215,11 +221,18 @@ class GraphedSampler:
         cond, mask = sample["lm_outputs"], sample["lm_mask"]
         if guidance_scale != 1:
             assert xs[0].shape[0] * 2 == cond.shape[0], "classifier-free guidance: lm_outputs = [uncond | cond]"
+        # micro-conditioning the sample carries (scale, watermark_score, ...), as Diffusion.sample passes it on
+        # (reference diffusion.py:194-196); one value per row of the model's batch (2B under guidance)
+        micros = {k: torch.as_tensor(v, device=xs[0].device).reshape(-1).float()
+                  for k, v in self.pipe.get_micro_conditioning(sample).items()}
         key = (tuple(tuple(x.shape) for x in xs), tuple(cond.shape), int(num_inference_steps), ddim_eta, float(guidance_scale),
-               torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else None)
-        ent = self._graphs.get(key) or self._build(key, xs, cond, mask, int(num_inference_steps), ddim_eta, float(guidance_scale))
+               torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else None,
+               tuple(sorted((k, tuple(v.shape)) for k, v in micros.items())))
+        ent = self._graphs.get(key) or self._build(key, xs, cond, mask, int(num_inference_steps), ddim_eta, float(guidance_scale), micros)
         for sx, x in zip(ent["x"], xs):
             sx.copy_(x)
+        for k, v in micros.items():
+            ent["micros"][k].copy_(v)
         ce, cs, cm = model.vision_model.forward_conditioning(cond, mask)
         ent["ce"].copy_(ce)
         ent["cs"].copy_(cs)

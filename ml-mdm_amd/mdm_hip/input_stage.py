@@ -39,10 +39,36 @@ class StagedBatch(dict):
         if ev is not None:
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)
-            for v in dict.values(self):
+            # the tensors were allocated on the copy stream: tell the caching allocator who else reads them
+            for v in list(dict.values(self)) + [self._u8]:
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(cur)
         return self
+
+    # every way of getting a tensor out of the batch orders the consumer stream behind the copy stream first
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return dict.items(self.ready())
+
+    def values(self):
+        return dict.values(self.ready())
+
+    def keys(self):
+        return dict.keys(self.ready())
+
+    def __iter__(self):
+        return dict.__iter__(self.ready())
+
+    def pop(self, key, *default):
+        return dict.pop(self.ready(), key, *default)
+
+    def popitem(self):
+        return dict.popitem(self.ready())
+
+    def copy(self):
+        return dict(self.ready())
 
     def __getitem__(self, key):
         self.ready()

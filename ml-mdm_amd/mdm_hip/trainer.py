@@ -1,26 +1,318 @@
-"""The train step of the headline metric: forward (+bf16 autocast) -> loss -> backward ->
-gradient all-reduce -> clip -> AdamW -> EMA -> zero-grad.
+"""The train step of the headline metric behind the reference's own entry point.
 
-Mirrors ``ml_mdm.trainer.train_batch`` (reference trainer.py:13-96), the optimizer set-up of
-``clis/train_parallel.py:122-134`` (AdamW, weight_decay 0, eps 1e-8) and ``ModelEma.update``
-(models/model_ema.py:25-34; the EMA here tracks parameters -- the model has no persistent
-buffers).  bf16 needs no loss scaling, so the reference's GradScaler is not reproduced.
-On the GPU the optimizer tail is fused: gradients land directly in a flat arena
-and ``mdm_sumsq`` + ``mdm_adamw_ema_step`` do clip + AdamW + EMA + zero-grad in two streaming passes.
+``train_batch(model, sample, optimizer, scheduler, logger, args, grad_scaler, accumulate_gradient,
+num_grad_accumulations, ema_model, loss_factor)`` has the signature, the order of operations, the logging and the
+return value of ``ml_mdm.trainer.train_batch`` (reference trainer.py:13-96), so ``clis/train_parallel.py`` runs
+on it with one import swapped (``from mdm_hip import trainer``).  What it does underneath depends on the model:
+
+* **fused path** -- the vision model is this package's UNet / NestedUNet on an MI355X, the optimizer is the
+  ``torch.optim.AdamW`` / ``Adam`` the CLI builds (train_parallel.py:122-134) and the wrapper around ``model.model``
+  is either none (one GPU) or ``mdm_hip.distributed.DataParallel``.  On the first call the step ADOPTS what the CLI
+  built: the parameters move into one flat fp32 arena (same ``nn.Parameter`` objects, new storage), the optimizer's
+  moments and the ``ModelEma`` copy's parameters become views of flat arenas as well -- so ``optimizer.state_dict()``,
+  ``ema_model.save()`` and ``vision_model.save()`` keep working -- and from then on backward kernels ADD parameter
+  gradients straight into a flat gradient arena (``ops.set_grad_sink``), and clip + AdamW + EMA + zero-grad are two
+  streaming passes (``mdm_sumsq`` + ``mdm_adamw_ema_step``).  Gradient accumulation
+  micro-steps (``accumulate_gradient=True`` under ``model.model.no_sync()``, train_parallel.py:196-230) simply keep
+  adding into the arena; the learning rate is read from ``optimizer.param_groups`` every step, so any scheduler works.
+* **plain path** -- anything else (CPU tensors, torch's DistributedDataParallel, another optimizer): the reference's
+  sequence with torch's own pieces -- autograd accumulation, ``clip_grad_norm_``, ``optimizer.step()``,
+  ``ema_model.update()`` -- the denoiser's kernels are still this package's.  ``bench.py --reference-loop`` times it.
+
+bf16 autocast needs no loss scaling: the reference's ``GradScaler`` (trainer.py:43-53) multiplies the loss by a
+power of two and divides the gradients by it again, which is exact in bf16/fp32 short of overflow; the fused path
+therefore leaves the scaler alone (the plain path drives it like the reference does).
+
+``TrainStep`` is the same fused step as a self-contained object (tests, tools).
 """
 import math
 
 import torch
 
 from . import ops
-from .distributed import GradReducer
+from .distributed import DataParallel, GradReducer
 
 
+class FusedState:
+    """Flat fp32 arenas for parameters / gradients / Adam moments / EMA of one vision model, and the fused optimizer
+    tail over them.  Arena order = reverse registration order (the order backward produces gradients)."""
+
+    def __init__(self, net, reducer=None, bucket_mb=256.0, wire_dtype=None, use_ema=True, async_wgrad=True):
+        self.net = net
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.reducer = reducer if reducer is not None else GradReducer(self.params, bucket_mb=bucket_mb, wire_dtype=wire_dtype)
+        self.reducer.broadcast_parameters(0)
+        flat = torch.empty_like(self.reducer.flat)
+        self.slices = {}
+        off = 0
+        with torch.no_grad():
+            for p in reversed(self.params):
+                n = p.numel()
+                flat[off:off + n].copy_(p.reshape(-1))
+                p.data = flat[off:off + n].view_as(p)
+                self.slices[id(p)] = (off, n)
+                off += n
+        self.flat_p = flat
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.flat_ema = flat.clone() if use_ema else None
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)   # optimizer step number, on the device
+        self.reducer.rebind()
+        self.async_wgrad = async_wgrad
+        self.activate()
+
+    def activate(self):
+        """route the backward kernels' parameter gradients into this state's arena"""
+        ops.set_grad_sink(self.reducer)
+        ops.enable_async_wgrad(self.async_wgrad)
+        ops.enable_deferred_wgrad(self.async_wgrad, max_group=32 if self.reducer.world == 1 else 13)
+        ops.invalidate_packed_weights()
+
+    def view(self, arena, p):
+        off, n = self.slices[id(p)]
+        return arena[off:off + n].view_as(p)
+
+    def finish_backward(self):
+        """everything that has to be in the gradient arena before the optimizer reads it"""
+        ops.flush_wgrad_queue()
+        ops.join_side_stream()
+        self.reducer.finish()
+
+    def optimizer_step(self, lr, betas, eps, weight_decay, clip_norm, ema_decay, dtype):
+        """clip + AdamW + EMA + zero-grad over the arenas (two launches) and the re-pack of the kernel-layout weights.
+        A non-finite gradient norm skips the update, clears the gradients and does not advance the step number."""
+        ops.sumsq(self.reducer.flat, out=self.gnorm_sq, step_counter=self.step_dev)
+        ops.adamw_ema_step(self.flat_p, self.reducer.flat, self.m, self.v, self.flat_ema, self.gnorm_sq, lr, betas[0], betas[1],
+                           eps, weight_decay, 0, clip_norm, ema_decay, zero_grad=True, step_dev=self.step_dev)
+        ops.repack_all(dtype)   # one launch instead of one per weight
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the reference's entry point
+# --------------------------------------------------------------------------------------------------------------
+def _vision_model(model):
+    core = getattr(model.model, "module", model.model)
+    return core.vision_model
+
+
+def _adopt(model, optimizer, ema_model):
+    """-> FusedState for (model, optimizer, ema_model), built on first use and cached on the optimizer; None when the
+    combination does not qualify for the fused path (see the module docstring)."""
+    st = getattr(optimizer, "_mdm_fused", None)
+    if st is not None:
+        return st if st is not False else None
+
+    def no(reason):
+        optimizer._mdm_fused = False
+        optimizer._mdm_fused_reason = reason
+        return None
+
+    from .unet import UNet
+
+    wrapped = model.model
+    net = _vision_model(model)
+    if isinstance(wrapped, torch.nn.parallel.DistributedDataParallel):
+        return no("torch DistributedDataParallel owns the gradient buckets (use mdm_hip.distributed.DataParallel)")
+    if not isinstance(net, UNet):
+        return no("vision model is not an mdm_hip UNet")
+    params = [p for p in net.parameters() if p.requires_grad]
+    if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+        return no("parameters are not fp32 tensors on the GPU")
+    if type(optimizer) not in (torch.optim.AdamW, torch.optim.Adam) or len(optimizer.param_groups) != 1:
+        return no("optimizer is not a single-group torch Adam / AdamW")
+    grp = optimizer.param_groups[0]
+    if grp.get("amsgrad") or grp.get("maximize") or (type(optimizer) is torch.optim.Adam and grp.get("weight_decay", 0) != 0
+                                                      and not grp.get("decoupled_weight_decay", False)):
+        return no("optimizer options without a fused counterpart (amsgrad / maximize / L2 weight decay)")
+    if [id(p) for p in grp["params"]] != [id(p) for p in params]:
+        return no("optimizer does not hold exactly the vision model's parameters")
+    ema_net = None
+    if ema_model is not None:
+        ema_net = ema_model.module
+        # ModelEma.update walks the state_dict: parameters AND persistent buffers (this package's nets have none)
+        if getattr(ema_model, "device", None) is not None or set(net.state_dict()) != {n for n, _ in net.named_parameters()} or \
+                [(n, tuple(p.shape)) for n, p in ema_net.named_parameters()] != [(n, tuple(p.shape)) for n, p in net.named_parameters()]:
+            return no("ModelEma on another device / of another shape / with persistent buffers")
+    reducer = wrapped.reducer if isinstance(wrapped, DataParallel) else \
+        GradReducer(params, group=None, world_override=1)   # an unwrapped model trains locally, whatever torch.distributed holds
+    had_state = {id(p): dict(optimizer.state.get(p, {})) for p in params}
+    st = FusedState(net, reducer=reducer, use_ema=ema_net is not None)
+    with torch.no_grad():
+        # the optimizer's moments (a resumed run has them) and step count move into the arenas; the entries the
+        # optimizer keeps are views, so optimizer.state_dict() / load_state_dict() round-trip as before
+        steps = 0
+        for p in params:
+            old = had_state[id(p)]
+            mv, vv = st.view(st.m, p), st.view(st.v, p)
+            if "exp_avg" in old:
+                mv.copy_(old["exp_avg"])
+                vv.copy_(old["exp_avg_sq"])
+                steps = max(steps, int(old["step"]))
+            optimizer.state[p] = {"step": None, "exp_avg": mv, "exp_avg_sq": vv}
+        st.step_dev.fill_(steps)
+        # the step number lives on the device (a skipped non-finite step does not advance it); the optimizer's "step"
+        # entries share one host tensor that is refreshed whenever somebody asks for the state_dict (checkpoint time)
+        step_host = torch.tensor(float(steps))
+        for p in params:
+            optimizer.state[p]["step"] = step_host
+        optimizer.register_state_dict_pre_hook(lambda opt, st=st, t=step_host: t.fill_(float(int(st.step_dev))))
+        if ema_net is not None:
+            by_name = dict(net.named_parameters())
+            for name, pe in ema_net.named_parameters():
+                ev = st.view(st.flat_ema, by_name[name])
+                ev.copy_(pe.detach())
+                pe.data = ev
+    optimizer._mdm_fused = st
+    return st
+
+
+def _loss_of(losses, weights):
+    return losses.mean() if weights is None else (losses * weights).sum() / weights.sum()
+
+
+def train_batch(model, sample, optimizer, scheduler, logger, args, grad_scaler=None, accumulate_gradient=False,
+                num_grad_accumulations=1, ema_model=None, loss_factor=1.0):
+    """One micro-step of ``ml_mdm.trainer.train_batch`` (reference trainer.py:13-96): same arguments, same return value
+    ``(loss_val, losses, times, x_t, means, targets)``; the caller wraps accumulation micro-steps in
+    ``model.model.no_sync()`` exactly as train_parallel.py:196-214 does."""
+    model.train()
+    lr = scheduler.get_last_lr()[0]
+    st = _adopt(model, optimizer, ema_model)
+    fp16 = bool(getattr(args, "fp16", False))
+    dev_type = "cuda" if next(_vision_model(model).parameters()).is_cuda else "cpu"
+    if st is not None and ops._grad_sink is not st.reducer:
+        st.activate()   # another FusedState (a second model in the same process) was used in between
+
+    if fp16:
+        with torch.autocast(dev_type, dtype=torch.bfloat16):
+            losses, times, x_t, means, targets, weights = model.get_loss(sample)
+            loss = _loss_of(losses, weights) * loss_factor
+            loss_val = loss.item()
+            if math.isnan(loss_val):
+                _skip_step(st, optimizer, loss, accumulate_gradient, args, fp16)
+                return loss_val, losses, times, x_t, means, targets
+            if num_grad_accumulations != 1:
+                loss = loss / num_grad_accumulations
+        if st is None and grad_scaler is not None:
+            grad_scaler.scale(loss).backward()
+        else:
+            loss.backward()
+    else:
+        losses, times, x_t, means, targets, weights = model.get_loss(sample)
+        loss = _loss_of(losses, weights)
+        loss_val = loss.item()
+        if math.isnan(loss_val):
+            _skip_step(st, optimizer, loss, accumulate_gradient, args, fp16)
+            if st is None:
+                optimizer.step()
+            scheduler.step()
+            return loss_val, losses, times, x_t, means, targets
+        loss.backward()   # (the reference divides by num_grad_accumulations only AFTER this, trainer.py:73-75: no effect)
+
+    if st is not None:
+        # also after an accumulation micro-step: nothing queued (grouped weight gradients, GroupNorm parameter rows) may
+        # cross into the next micro-step, where its ready() report would release a bucket before that step's own
+        # gradient is written; inside no_sync() the reducer's finish() joins nothing
+        st.finish_backward()
+    if not accumulate_gradient:
+        clip = float(getattr(args, "gradient_clip_norm", 2.0))
+        if st is not None:
+            grp = optimizer.param_groups[0]
+            decay = 0.0
+            if ema_model is not None:   # ModelEma.update (models/model_ema.py:25-34), warm-up included
+                decay = float(ema_model.counter >= ema_model.warmup_steps) * ema_model.decay
+                ema_model.counter += 1
+            st.optimizer_step(grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"], clip, decay,
+                              torch.bfloat16 if fp16 else torch.float32)
+            optimizer._opt_called = True   # the step happened (silences lr_scheduler's call-order warning)
+        else:
+            core = getattr(model.model, "module", model.model)
+            if fp16 and grad_scaler is not None:
+                grad_scaler.unscale_(optimizer)
+                torch.nn.utils.clip_grad_norm_(model.model.parameters(), clip)
+                grad_scaler.step(optimizer)
+                grad_scaler.update()
+            else:
+                torch.nn.utils.clip_grad_norm_(model.model.parameters(), clip)
+                optimizer.step()
+            ops.invalidate_packed_weights()
+            if ema_model is not None:
+                ema_model.update(core.vision_model)
+
+    if logger is not None and not accumulate_gradient:
+        logger.add_scalar("train/Loss", loss_val)
+        logger.add_scalar("lr", lr)
+    if not accumulate_gradient:
+        if st is None:
+            optimizer.zero_grad()
+        scheduler.step()
+    return loss_val, losses, times, x_t, means, targets
+
+
+def _skip_step(st, optimizer, loss, accumulate_gradient, args, fp16):
+    """NaN loss: drop the gradients accumulated so far and take no step (reference trainer.py:38-41, 64-69).  With
+    several ranks in a synchronised step the reference's early return deadlocks the ranks that did not see the NaN (they
+    wait for bucket all-reduces the returning rank never issues); here every rank still runs backward and the fused
+    optimizer, which skips the update ON THE DEVICE when the reduced gradient norm is not finite -- the same outcome
+    (no update, gradients cleared, step number not advanced) without a host-side branch that could diverge."""
+    if st is None:
+        optimizer.zero_grad()
+        return
+    if st.reducer.world > 1 and not accumulate_gradient:
+        loss.backward()
+        st.finish_backward()
+        grp = optimizer.param_groups[0]
+        st.optimizer_step(grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"], float(getattr(args, "gradient_clip_norm", 2.0)),
+                          1.0, torch.bfloat16 if fp16 else torch.float32)
+        return
+    st.finish_backward()    # nothing may still be adding into the arena
+    st.reducer.zero_grad()
+
+
+class ModelEma(torch.nn.Module):
+    """``ml_mdm.models.model_ema.ModelEma`` (reference models/model_ema.py:11-52): a deep copy of the vision model whose
+    state follows ``ema = decay * ema + (1 - decay) * model``.  Provided so the package is self-contained; the
+    reference's own class works with ``train_batch`` just as well (same attributes)."""
+
+    def __init__(self, model, decay=0.9999, warmup_steps=0, device=None):
+        super().__init__()
+        from copy import deepcopy
+
+        self.module = deepcopy(model)
+        self.module.eval()
+        self.decay, self.device, self.warmup_steps, self.counter = decay, device, warmup_steps, 0
+        if device is not None:
+            self.module.to(device=device)
+
+    def update(self, model):
+        decay = (self.counter >= self.warmup_steps) * self.decay
+        self.counter += 1
+        with torch.no_grad():
+            msd = model.state_dict()
+            for k, ema_v in self.module.state_dict().items():
+                mv = msd[k].detach()
+                if self.device:
+                    mv = mv.to(device=self.device)
+                ema_v.mul_(decay).add_(mv, alpha=1.0 - decay)
+
+    def save(self, fname, other_items=None):
+        ckpt = {"state_dict": self.module.state_dict()}
+        ckpt.update(other_items or {})
+        torch.save(ckpt, fname)
+
+    def load(self, fname):
+        ckpt = torch.load(fname, map_location="cpu")
+        mine = self.module.state_dict()
+        self.module.load_state_dict({k: v for k, v in ckpt["state_dict"].items() if k in mine}, strict=False)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# self-contained step object
+# --------------------------------------------------------------------------------------------------------------
 class TrainStep:
-    """fused=True (GPU): parameters, gradients, Adam moments and the EMA live in flat fp32 arenas; backward kernels
-    add parameter gradients straight into the gradient arena (ops.set_grad_sink) and the whole optimizer tail is
-    ``mdm_sumsq`` + ``mdm_adamw_ema_step`` (clip, AdamW, EMA, zero-grad in one pass).  fused=False keeps torch's
-    optimizer (CPU tests, or as a cross-check)."""
+    """fused=True (GPU): the arenas and the fused tail of ``FusedState`` with a fixed learning rate; one optimizer step
+    per call.  fused=False keeps torch's optimizer on the flat gradient arena (CPU tests, or as a cross-check)."""
 
     def __init__(self, pipeline, lr=5e-5, clip_norm=2.0, ema_decay=0.9999, bf16=True, use_ema=True,
                  bucket_mb=256.0, wire_dtype=None, fused=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
@@ -28,50 +320,34 @@ class TrainStep:
         self.pipeline = pipeline
         self.net = pipeline.get_model().vision_model
         self.params = [p for p in self.net.parameters() if p.requires_grad]
-        self.reducer = GradReducer(self.params, bucket_mb=bucket_mb, wire_dtype=wire_dtype)
-        self.reducer.broadcast_parameters(0)
         self.fused = self.params[0].is_cuda if fused is None else fused
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.clip_norm, self.bf16, self.ema_decay = clip_norm, bf16, ema_decay
         self.steps = 0
         if self.fused:
             pipeline.materialize_targets = False   # the fused loss kernel never forms the target tensor; nobody reads it here
-        if self.fused:
-            # flat parameter arena in the SAME order as the gradient arena (reverse registration order)
-            flat = torch.empty_like(self.reducer.flat)
-            off = 0
-            with torch.no_grad():
-                for p in reversed(self.params):
-                    n = p.numel()
-                    flat[off:off + n].copy_(p.reshape(-1))
-                    p.data = flat[off:off + n].view_as(p)
-                    off += n
-            self.flat_p = flat
-            self.m = torch.zeros_like(flat)
-            self.v = torch.zeros_like(flat)
-            self.flat_ema = flat.clone() if use_ema else None
-            self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
-            self.step_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)   # optimizer step number, on the device
-            self.reducer.rebind()
-            ops.set_grad_sink(self.reducer)
-            ops.enable_async_wgrad(async_wgrad)
-            ops.enable_deferred_wgrad(async_wgrad, max_group=32 if self.reducer.world == 1 else 13)
-            ops.invalidate_packed_weights()
+            self.state = FusedState(self.net, bucket_mb=bucket_mb, wire_dtype=wire_dtype, use_ema=use_ema, async_wgrad=async_wgrad)
+            self.reducer = self.state.reducer
             self.opt = None
             self.ema = None
         else:
+            self.reducer = GradReducer(self.params, bucket_mb=bucket_mb, wire_dtype=wire_dtype)
+            self.reducer.broadcast_parameters(0)
             self.opt = torch.optim.AdamW(self.params, lr=lr, betas=betas, weight_decay=weight_decay, eps=eps)
             self.ema = [p.detach().clone() for p in self.params] if use_ema else None
+
+    # the arenas under their historical names
+    flat_p = property(lambda self: self.state.flat_p)
+    m = property(lambda self: self.state.m)
+    v = property(lambda self: self.state.v)
+    flat_ema = property(lambda self: self.state.flat_ema)
+    step_dev = property(lambda self: self.state.step_dev)
 
     def ema_state(self):
         """name -> EMA tensor (views of the flat EMA arena in fused mode)"""
         names = {id(p): n for n, p in self.net.named_parameters()}
         if self.fused:
-            out, off = {}, 0
-            for p in reversed(self.params):
-                out[names[id(p)]] = self.flat_ema[off:off + p.numel()].view_as(p)
-                off += p.numel()
-            return out
+            return {names[id(p)]: self.state.view(self.state.flat_ema, p) for p in self.params}
         return {names[id(p)]: e for p, e in zip(self.params, self.ema)}
 
     def __call__(self, sample, **loss_kw):
@@ -79,7 +355,7 @@ class TrainStep:
         dev_type = "cuda" if self.params[0].is_cuda else "cpu"
         with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=self.bf16):
             losses, times, x_t, means, targets, weights = self.pipeline.get_loss(sample, **loss_kw)
-            loss = losses.mean() if weights is None else (losses * weights).sum() / weights.sum()
+            loss = _loss_of(losses, weights)
         if self.fused:
             # The loss is read where the reference reads it (trainer.py:37) -- by then the host has queued the whole
             # forward, and it queues the next step's forward while this step's backward runs -- but nothing branches on
@@ -88,14 +364,9 @@ class TrainStep:
             # early return (trainer.py:38-41), identical on every rank without a collective.
             loss_val = loss.item()
             loss.backward()
-            ops.flush_wgrad_queue()
-            ops.join_side_stream()
-            self.reducer.finish()
-            ops.sumsq(self.reducer.flat, out=self.gnorm_sq, step_counter=self.step_dev)
-            ops.adamw_ema_step(self.flat_p, self.reducer.flat, self.m, self.v, self.flat_ema, self.gnorm_sq, self.lr,
-                               self.betas[0], self.betas[1], self.eps, self.weight_decay, 0, self.clip_norm,
-                               self.ema_decay, zero_grad=True, step_dev=self.step_dev)
-            ops.repack_all(torch.bfloat16 if self.bf16 else torch.float32)   # one launch instead of one per weight
+            self.state.finish_backward()
+            self.state.optimizer_step(self.lr, self.betas, self.eps, self.weight_decay, self.clip_norm, self.ema_decay,
+                                      torch.bfloat16 if self.bf16 else torch.float32)
             self.steps += 1 if math.isfinite(loss_val) else 0
             return loss_val
         loss_val = loss.item()  # the reference syncs here every step (trainer.py:37)

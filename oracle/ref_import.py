@@ -30,7 +30,7 @@ _loaded = None
 
 
 def load():
-    """-> namespace with .config .unet .nested_unet .diffusion .samplers (reference modules)."""
+    """-> namespace with .config .unet .nested_unet .diffusion .samplers .trainer .model_ema (reference modules)."""
     global _loaded
     if _loaded is not None:
         return _loaded
@@ -59,10 +59,18 @@ def load():
         b3.session = _stub("boto3.session")
         _stub("boto3.s3")
         _stub("boto3.s3.transfer", TransferConfig=object)
+    if "torch.utils.tensorboard" not in sys.modules:   # trainer.py:10 (type annotations only)
+        try:
+            import torch.utils.tensorboard  # noqa: F401
+        except Exception:
+            import torch.utils
+
+            torch.utils.tensorboard = _stub("torch.utils.tensorboard", SummaryWriter=object)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
-    from ml_mdm import config, diffusion, samplers  # noqa: E402
-    from ml_mdm.models import nested_unet, unet  # noqa: E402
+    from ml_mdm import config, diffusion, samplers, trainer  # noqa: E402
+    from ml_mdm.models import model_ema, nested_unet, unet  # noqa: E402
 
-    _loaded = types.SimpleNamespace(config=config, unet=unet, nested_unet=nested_unet, diffusion=diffusion, samplers=samplers)
+    _loaded = types.SimpleNamespace(config=config, unet=unet, nested_unet=nested_unet, diffusion=diffusion, samplers=samplers,
+                                    trainer=trainer, model_ema=model_ema)
     return _loaded

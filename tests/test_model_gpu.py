@@ -455,3 +455,33 @@ def test_graphed_sampler_matches_eager_sampler(name, mode):
             assert O.rel_l2(out, eager) < 1e-6, rep
     pipe.sampler.device_rng = None
     assert len(gs._graphs) == 1
+
+
+def test_graphed_sampler_passes_micro_conditioning_and_handles_one_step_schedules():
+    """GraphedSampler.sample must hand the sample's micro-conditioning (``scale`` ...) to the denoiser
+    like Diffusion.sample does (reference diffusion.py:194-196) -- different values, different images -- and a
+    1-step schedule must survive the warm-up passes; without ``seed=`` the first call starts the generator at
+    (seed, 0) like the eager sampler after use_device_rng(seed)."""
+    from mdm_hip.graph import GraphedSampler
+
+    model, _, _ = PC.build_module("mini_unet")
+    pipe = _pipeline("mini_unet", model).to(torch.device("cuda:0"))
+    pipe.eval()
+    inp = PC.inputs("mini_unet")
+    cond, mask = inp["cond"].cuda(), inp["mask"].cuda()
+    g = torch.Generator().manual_seed(41)
+    start = torch.randn(2, 3, 16, 16, generator=g).cuda()
+    outs = {}
+    with torch.no_grad():
+        for tag, micros in (("default", {}), ("scale", {"scale": torch.tensor([7.0, 40.0]).cuda()})):
+            for n in (4, 1):
+                pipe.sampler.use_device_rng(99, "cuda:0")
+                eager = pipe.sampler.sample(pipe.get_model(), start.clone(), cond, mask, micros, resample_steps=True,
+                                            num_inference_steps=n, ddim_eta=None)
+                gs = GraphedSampler(pipe, seed=99)
+                smp = dict({"lm_outputs": cond, "lm_mask": mask}, **micros)
+                out = gs.sample(2, smp, 16, torch.device("cuda:0"), num_inference_steps=n, start_noise=start)   # no seed=
+                assert O.rel_l2(out, eager) < 1e-6, (tag, n)
+                outs[(tag, n)] = out
+    pipe.sampler.device_rng = None
+    assert O.rel_l2(outs[("scale", 4)], outs[("default", 4)]) > 1e-4
