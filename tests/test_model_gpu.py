@@ -485,3 +485,56 @@ def test_graphed_sampler_passes_micro_conditioning_and_handles_one_step_schedule
                 outs[(tag, n)] = out
     pipe.sampler.device_rng = None
     assert O.rel_l2(outs[("scale", 4)], outs[("default", 4)]) > 1e-4
+
+
+@pytest.mark.parametrize("name", ["nested1024_ddpm", "unet64_ddpm50", "unet64_ddim100"])
+def test_long_horizon_sampling_matches_reference(name, tmp_path):
+    """Long sampling runs at FULL size against the real reference pipeline (tests/golden/long_sampling.pt, made by
+    oracle/make_golden.py long): BASELINE.json configs[4] -- the 64+256+1024 NestedUNet, ancestral DDPM (ddim_eta=1,
+    generate_sample.py:546-551), 25 steps, B=1, weights round-tripped through UNet.save -> UNet.load -- and the 64x64
+    U-Net over 50 DDPM / 100 DDIM steps.  The reference consumed, draw by draw, the host replay of the numbers the step
+    kernel generates from DeviceRng(LONG_SEED) (oracle/philox_ref.py), so both sides see identical noise.
+    Gate: 1e-3 rel-L2 in fp32 (north_star); the bf16-autocast error of the same run is printed."""
+    import make_golden as MG
+    from mdm_hip import diffusion as D
+    from mdm_hip import samplers as S
+
+    arch, B, steps, eta, skw = MG.LONG_CASES[name]
+    gold = torch.load(os.path.join(GOLD, "long_sampling.pt"), weights_only=False)[name]
+    src, sd = PC.full_module(arch)
+    ck = str(tmp_path / "vis_model_synthetic.pth")
+    src.save(ck, other_items={"batch_num": 7})
+    del src
+    model, _ = PC.full_module(arch, seed=3, param_seed=5)     # other values: everything must come from the file
+    assert model.load(ck)["batch_num"] == 7
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    nested = len(PC.FULL[arch][1]) > 1
+    scfg = S.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
+                           loss_target_type="DDPM", threshold_function="CLIP", **skw)
+    if nested:
+        pipe = D.NestedDiffusion(model, D.NestedDiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False,
+                                                                use_double_loss=True, no_use_residual=True))
+    else:
+        pipe = D.Diffusion(model, D.DiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False))
+    pipe = pipe.to(torch.device("cuda:0"))
+    pipe.eval()
+    inp = PC.full_inputs(arch)
+    cond, mask = inp["cond"][:B].cuda(), inp["mask"][:B].cuda()
+    start = [t.cuda() for t in MG.long_start_noise(name)]
+    errs = {}
+    for mode in ("fp32", "bf16"):
+        pipe.sampler.use_device_rng(MG.LONG_SEED, "cuda:0")
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "bf16"):
+            out = pipe.sampler.sample(pipe.get_model(), [t.clone() for t in start] if nested else start[0].clone(), cond, mask, {},
+                                      resample_steps=True, num_inference_steps=steps, ddim_eta=eta)
+        assert tuple(out.shape) == gold["shape"]
+        if mode == "fp32":
+            # the same number of noise draws as the reference made
+            per_step = sum((t.numel() + 3) // 4 for t in start)
+            assert int(pipe.sampler.device_rng.state[1]) == (gold["draws"] // len(start)) * per_step
+            PC.check_summary(out.float(), gold["out"], "long." + name, 1e-3)
+        st = max(1, out.shape[-1] // 64)
+        errs[mode] = O.rel_l2(out.float()[..., ::st, ::st], gold["out"]["sub"])
+    pipe.sampler.device_rng = None
+    print("[long sampling %s: %d steps, B=%d] rel-L2 vs the reference: fp32 %.3e, bf16 autocast %.3e" % (name, steps, B, errs["fp32"], errs["bf16"]))
