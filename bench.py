@@ -15,6 +15,14 @@ timed region.  Rank 0 prints ONE JSON line (contract in the task statement) with
   cpu_baseline  the CPU oracle (a port of the reference path) on this box's host cores, rank 0 / N = 1 only
   sampling      ms per denoise step (DDIM, whole iteration: model + fused update)
   nested256     BASELINE.json configs[2] (cc12m_256x256 NestedUNet, bf16, batch 16): steps/s of the same train step
+  reference_loop  the SAME entry point on its plain path (autograd gradient accumulation, GradScaler, clip_grad_norm_,
+                torch AdamW, per-tensor ModelEma -- what the unchanged CLI objects do without the arena adoption)
+  nested1024_sampling  BASELINE.json configs[4]: ms per DDPM iteration of the 64+256+1024 NestedUNet at batch 4 and
+                the 250-step total (generate_sample.py:546-551)
+
+The timed step IS ``mdm_hip.trainer.train_batch`` -- the reference's ``trainer.train_batch`` signature
+(trainer.py:13-25) called the way clis/train_parallel.py:122-230 calls it (torch AdamW lr 5e-5, warm-up LambdaLR,
+ModelEma 0.9999, gradient_clip_norm 2, bf16 autocast): one import swap in the CLI gives this number.
 """
 import argparse
 import json
@@ -137,6 +145,38 @@ def cpu_baseline(workload, batch_ref):
     }
 
 
+def make_step(pipe, bf16, world, plain=False, bucket_mb=256.0, wire=None, serial_wgrad=False, force_collectives=False, torch_ddp=False):
+    """The objects clis/train_parallel.py:107-154 builds around the pipeline, and the step closure of its loop
+    (:216-230): -> (step(sample) -> loss value, optimizer)"""
+    import types
+
+    from mdm_hip import distributed as mdist
+    from mdm_hip import trainer
+
+    vm = pipe.model.vision_model
+    opt = torch.optim.AdamW(vm.parameters(), lr=5e-5, weight_decay=0, eps=1e-8)                 # :122-128
+    warm = 1000
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: float(max(1, it)) / warm if max(1, it) < warm else 1.0)   # lr_scaler.py:18-28
+    if torch_ddp:                                                                                 # :147-151, unchanged
+        pipe.model = torch.nn.parallel.DistributedDataParallel(pipe.model, device_ids=[torch.cuda.current_device()])
+    elif world > 1 or force_collectives:                                                          # ... or our wrapper in its place
+        pipe.model = mdist.DataParallel(pipe.model, device_ids=[torch.cuda.current_device()], bucket_mb=bucket_mb,
+                                        wire_dtype=wire, force_collectives=force_collectives)
+    ema = trainer.ModelEma(vm)                                                                    # :157
+    args = types.SimpleNamespace(fp16=bf16, gradient_clip_norm=2.0)
+    scaler = torch.amp.GradScaler("cuda") if bf16 else None                                      # :113-116
+    if plain:
+        opt._mdm_fused = False
+    if serial_wgrad:
+        os.environ["MDM_HIP_SERIAL_WGRAD"] = "1"
+
+    def step(sample):
+        return trainer.train_batch(pipe, sample, opt, sched, None, args, grad_scaler=scaler, accumulate_gradient=False,
+                                   num_grad_accumulations=1, ema_model=ema, loss_factor=1.0)[0]
+
+    return step, opt
+
+
 def timed_steps(step, sample, warmup, steps, sync):
     for _ in range(warmup):
         step(sample)
@@ -164,13 +204,23 @@ def main():
     ap.add_argument("--serial-wgrad", action="store_true",
                     help="diagnostic: weight gradients on the main stream (uncontended per-kernel durations for profiling)")
     ap.add_argument("--no-nested", action="store_true", help="skip the nested256 (configs[2]) sub-measurement")
+    ap.add_argument("--no-reference-loop", action="store_true", help="skip the plain-path (torch optimizer / EMA / autograd accumulation) leg")
+    ap.add_argument("--reference-loop", action="store_true", help="run the plain-path leg also when N > 1 (torch DDP, as the unchanged CLI)")
+    ap.add_argument("--no-nested1024", action="store_true", help="skip the nested-1024 (configs[4]) sampling leg")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: run the gradient buckets through RCCL anyway (world-of-one process group)")
     ap.add_argument("--sample-batch", type=int, default=None)
     args = ap.parse_args()
 
     from mdm_hip import distributed as mdist
     from mdm_hip import ops
-    from mdm_hip.trainer import TrainStep
 
+    if args.force_collectives and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        dist.init_process_group(backend=os.environ.get("MDM_DIST_BACKEND", "nccl"), init_method="env://", world_size=1, rank=0)
     # MDM_DIST_BACKEND=gloo + MDM_BENCH_DEVICE=0 let two ranks share ONE GPU (development check of the N > 1 path
     # on the single-GPU box); the driver's real runs use RCCL with one GPU per rank
     local, rank, world = mdist.init_distributed_singlenode(backend=os.environ.get("MDM_DIST_BACKEND"))
@@ -189,9 +239,11 @@ def main():
         torch.cuda.synchronize()
 
     pipe, side = build(args.workload, device)
-    step = TrainStep(pipe, bf16=bf16, bucket_mb=args.bucket_mb, wire_dtype=wire, async_wgrad=not args.serial_wgrad)
+    step, opt = make_step(pipe, bf16, world, bucket_mb=args.bucket_mb, wire=wire, serial_wgrad=args.serial_wgrad,
+                          force_collectives=args.force_collectives)
     sample = synthetic_batch(batch, side, device, seed=1234 + rank)
     dt = timed_steps(step, sample, args.warmup, args.steps, sync)
+    assert getattr(opt, "_mdm_fused", False) not in (None, False), getattr(opt, "_mdm_fused_reason", "the fused path did not engage")
     if world > 1:
         tt = torch.tensor([dt], device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -252,12 +304,12 @@ def main():
     # BASELINE.json configs[2]: the nested 64+256 train step at batch 16, same protocol, fewer steps
     nested = None
     if args.workload == "unet64" and not args.no_nested and bf16:
-        del step
+        del step, opt
         ops.set_grad_sink(None)
         pipe = sample = None
         torch.cuda.empty_cache()
         npipe, nside = build("nested256", device)
-        nstep = TrainStep(npipe, bf16=True, bucket_mb=args.bucket_mb, wire_dtype=wire)
+        nstep, nopt = make_step(npipe, True, world, bucket_mb=args.bucket_mb, wire=wire)
         nsample = synthetic_batch(16, nside, device, seed=99 + rank)
         nsteps = max(3, min(args.steps, 10))
         ndt = timed_steps(nstep, nsample, 2, nsteps, sync)
@@ -266,10 +318,72 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             ndt = float(tt.item())
         nflop = 3 * FWD_GFLOP_PER_SAMPLE["nested256"] * 16 / 1e3
+        assert getattr(nopt, "_mdm_fused", False) not in (None, False)
         nested = {"workload": "cc12m_256x256 NestedUNet (64+256) train step, bf16, per-GPU batch 16", "steps": nsteps,
                   "ms_per_step": round(ndt / nsteps * 1e3, 3), "steps_per_s_whole_job": round(world * nsteps / ndt, 4),
                   "step_algorithmic_tflop": round(nflop, 2),
                   "step_mfma_roofline_frac": round(nflop / (ndt / nsteps) / PEAK_BF16_TFLOPS, 4)}
+
+    # the same entry point on its PLAIN path: what the CLI's own objects do when nothing is adopted into arenas
+    ref_loop = None
+    if args.workload == "unet64" and bf16 and not args.no_reference_loop and (world == 1 or args.reference_loop):
+        try:
+            nstep = nopt = npipe = nsample = None
+            ops.set_grad_sink(None)
+            ops.enable_async_wgrad(False)
+            ops.enable_deferred_wgrad(False)
+            torch.cuda.empty_cache()
+            rpipe, rside = build("unet64", device)
+            rstep, ropt = make_step(rpipe, True, world, plain=True, torch_ddp=world > 1)
+            rsample = synthetic_batch(batch, rside, device, seed=1234 + rank)
+            rsteps = max(2, min(args.steps, 4))
+            rdt = timed_steps(rstep, rsample, 1, rsteps, sync)
+            assert getattr(ropt, "_mdm_fused", None) is False
+            ref_loop = {"ms_per_step": round(rdt / rsteps * 1e3, 3), "steps_per_s_whole_job": round(world * rsteps / rdt, 4), "steps": rsteps,
+                        "what": "mdm_hip.trainer.train_batch, plain path: HIP denoiser kernels, but autograd gradient accumulation, "
+                                "GradScaler, clip_grad_norm_, torch.optim.AdamW, per-tensor ModelEma.update"
+                                + (", torch DistributedDataParallel" if world > 1 else "")}
+            del rstep, ropt, rpipe
+            torch.cuda.empty_cache()
+        except Exception as ex:   # secondary leg: never take the headline line down
+            ref_loop = {"error": str(ex)[:200]}
+
+    # BASELINE.json configs[4]: nested 64+256+1024 sampling, ancestral DDPM, batch 4 (generate_sample.py:546-551), bf16
+    n1024 = None
+    if args.workload == "unet64" and bf16 and world == 1 and not args.no_nested1024 and not args.no_sampling:
+        try:
+            import mdm_hip
+            from mdm_hip import configs, diffusion, samplers
+            from mdm_hip.graph import GraphedSampler
+            from mdm_hip.testing import randomize_zero_params
+
+            sc = samplers.SamplerConfig(num_diffusion_steps=1000, schedule_type="DEEPFLOYD", prediction_type="V_PREDICTION",
+                                        loss_target_type="DDPM", schedule_shifted=True, rescale_signal=1, schedule_shifted_power=2)
+            torch.manual_seed(0)
+            net = mdm_hip.NestedUNet(3, 3, configs.nested1024_config(2048))
+            net.load_state_dict(randomize_zero_params(net.state_dict(), seed=1))
+            p4 = diffusion.NestedDiffusion(net, diffusion.NestedDiffusionConfig(sampler_config=sc, use_vdm_loss_weights=False,
+                                                                                use_double_loss=True, no_use_residual=True)).to(device)
+            s4 = synthetic_batch(4, 64, device, seed=7)
+            n_it = 6
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                gs = GraphedSampler(p4, seed=7)
+                gs.sample(4, s4, 1024, device, num_inference_steps=n_it, ddim_eta=1)
+                sync()
+                ts = time.perf_counter()
+                out4 = gs.sample(4, s4, 1024, device, num_inference_steps=n_it, ddim_eta=1)
+                sync()
+                ms4 = (time.perf_counter() - ts) / n_it * 1e3
+            n1024 = {"workload": "flickr1024 NestedUNet (64+256+1024) DDPM sampling (ddim_eta=1), batch 4, bf16, synthetic checkpoint",
+                     "ms_per_denoise_step": round(ms4, 3), "timed_steps": n_it, "seconds_per_250_steps": round(ms4 * 250 / 1e3, 3),
+                     "images_per_s_at_250_steps": round(4 / (ms4 * 250 / 1e3), 4), "finite": bool(torch.isfinite(out4).all()),
+                     "alg_tflop_per_step": round(4 * 1018.6 / 1e3, 3),
+                     "mfma_roofline_frac": round(4 * 1018.6e9 / (ms4 / 1e3) / (PEAK_BF16_TFLOPS * 1e12), 4),
+                     "sampler": "one hipGraph replay per iteration (GraphedSampler), CFG off"}
+            del gs, p4, net
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            n1024 = {"error": str(ex)[:200]}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -297,13 +411,16 @@ def main():
                 "samples_per_s": round(steps_per_s * batch, 2),
                 "step_algorithmic_tflop": round(alg_tflop_step, 2),
                 "step_mfma_roofline_frac": round(alg_tflop_step / (ms / 1e3) / (PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS), 4),
-                "comm": {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
-                         "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+                "comm": {"backend": dist.get_backend() if dist.is_initialized() else None, "world_size": world, "forced_collectives": bool(args.force_collectives),
+                         "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.is_initialized() else None,
                          "bucket_mb": args.bucket_mb, "wire_dtype": "bf16" if args.wire_bf16 else "fp32"},
             },
             "roofline": roof,
             "sampling": samp,
             "nested256": nested,
+            "reference_loop": ref_loop,
+            "nested1024_sampling": n1024,
+            "entry_point": "mdm_hip.trainer.train_batch (reference trainer.py:13-25 signature) on torch AdamW + LambdaLR + ModelEma objects, fused arena path",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, batch)

@@ -26,6 +26,7 @@ therefore leaves the scaler alone (the plain path drives it like the reference d
 ``TrainStep`` is the same fused step as a self-contained object (tests, tools).
 """
 import math
+import os
 
 import torch
 
@@ -137,7 +138,8 @@ def _adopt(model, optimizer, ema_model):
     reducer = wrapped.reducer if isinstance(wrapped, DataParallel) else \
         GradReducer(params, group=None, world_override=1)   # an unwrapped model trains locally, whatever torch.distributed holds
     had_state = {id(p): dict(optimizer.state.get(p, {})) for p in params}
-    st = FusedState(net, reducer=reducer, use_ema=ema_net is not None)
+    # MDM_HIP_SERIAL_WGRAD=1 (profiling aid, bench.py --serial-wgrad): weight gradients on the main stream
+    st = FusedState(net, reducer=reducer, use_ema=ema_net is not None, async_wgrad=os.environ.get("MDM_HIP_SERIAL_WGRAD", "0") != "1")
     with torch.no_grad():
         # the optimizer's moments (a resumed run has them) and step count move into the arenas; the entries the
         # optimizer keeps are views, so optimizer.state_dict() / load_state_dict() round-trip as before
