@@ -117,14 +117,17 @@ int mdm_colsum(const void* x, float* out, float* ws, int M, int C, int accumulat
  *   ceil(C / 256); total_blocks = the sum).  dres (same shape as x, may be
  *   NULL) is added into dx: the gradient that reaches x through the residual branch of the block the norm opens
  *   (h = x + f(norm(x)), unet.py:238, 309, 312) -- saves the separate accumulation kernel of the autograd engine.
+ *   dres2 (ABI 3, may be NULL): a second such gradient -- x is also a skip activation consumed by the up path
+ *   (unet.py:883-897, 545-547), whose gradient would otherwise be added to dx by one more elementwise kernel.
  *   ws (fp32) size from mdm_gn_plan (valid for both directions).
  */
 int mdm_gn_plan(int N, int HW, int C, int G, size_t* ws_bytes);
 int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, const void* film, void* y, float* stats,
                float* coef, float* ws, int N, int HW, int C, int G, float eps, int act, int dtype, void* stream);
 int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* film,
-               const float* stats, const float* coef, const void* dres, void* dx, float* dgamma, float* dbeta,
-               void* dfilm, float* ws, int N, int HW, int C, int G, int act, int accumulate, int dtype, void* stream);
+               const float* stats, const float* coef, const void* dres, const void* dres2, void* dx, float* dgamma,
+               float* dbeta, void* dfilm, float* ws, int N, int HW, int C, int G, int act, int accumulate, int dtype,
+               void* stream);
 int mdm_gn_param_reduce_multi(const void* table, int n, int total_blocks, void* stream);
 int mdm_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int R, int D, float eps,
                int dtype, void* stream);

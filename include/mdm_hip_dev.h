@@ -13,6 +13,10 @@ int mdm_conv_fwd_tile(int M, int Cout, int dtype);
 /* host-only: 128 or 256 (square output tile edge) mdm_conv_wgrad will use */
 int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype);
 
+/* development knobs of the GEMM kernels (all 0 in the product): 1 = epilogues skip their global stores (measures what
+ * the store phase costs), 2 = force the forward tile (128128 / 256192 / 256256).  Experiments recorded in DESIGN.md. */
+int mdm_dev_set_knob(int idx, int value);
+
 #ifdef __cplusplus
 }
 #endif

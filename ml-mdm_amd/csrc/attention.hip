@@ -866,6 +866,337 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// backward for SHORT sequences (bf16, L <= 256 queries, S <= 64 text keys): one block per (batch, head).
+// At the 16x16 level of the 64x64 U-Net (26 of its 31 attention layers: L = 256, d = 96) the two streaming kernels
+// above run 4 key / query tiles per block: every tile costs a global fetch, an LDS commit and two barriers for ~36
+// MFMAs per wave, and the K / V (Q / dO) rows of a head are re-streamed by each of its 4 + 5 blocks -- 0.13 PF.  Here a
+// head's operands become LDS-resident once per phase and the tile loops run without a barrier:
+//   phase 0  Q and dO tiles of the head -> LDS; lse (base 2) and delta = rowsum(dO * O) rows -> LDS
+//   phase 1  dK / dV: a wave owns 16 keys (K, V fragments in registers), walks the resident query tiles
+//            (the inner loop of attn_bwd_dkv_kernel, KT = 1); 128 keys per pass, text keys = one more pass
+//   phase 2  dQ: K / V tiles -> LDS (<= 3 key tiles at a time, the text tile is one of them), a wave owns 16 queries
+//            (Q, dO fragments in registers; the inner loop of attn_bwd_dq_kernel, QT = 1); 128 queries per pass
+// Same arithmetic, operand layouts and rounding points as the two-kernel path (which stays for long sequences and fp32).
+// ---------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
+  using T = bf16;
+  using G = AttnGeom<T, D>;
+  constexpr int KSTEPS = G::KSTEPS, DS = G::DS, DT = G::DT, CPR = G::CPR, NAT = G::NAT_BYTES;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const lse_self = reinterpret_cast<float*>(smem + 8 * NAT);   // [256] each, base-2 domain
+  float* const lse_cross = lse_self + 256;
+  float* const del_self = lse_cross + 256;
+  float* const del_cross = del_self + 256;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int quad = lane >> 4, l16 = lane & 15;
+  const TrOff<D> troff(quad, l16);
+  // The heads of one batch element read neighbouring 2 d-byte pieces of the same qkv / out rows: with d = 96 a head's
+  // piece (192 B) shares its 128-byte lines with the next head's, so heads on different XCDs fetch those lines twice
+  // (measured: phase 0 at 1.6 TB/s).  The remap puts consecutive (batch, head) pairs on one XCD, where the L2 merges them.
+  const int bh = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int b = bh / p.H, h = bh - b * p.H;
+  const T* Q = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * D;
+  const T* DO = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.o_bs + (size_t)h * D;
+  const bool has_c = p.kc != nullptr;
+  const int nq = (p.L + 63) >> 6;             // query tiles = self key tiles (<= 4)
+  const float c2 = p.scale * LOG2E;
+
+  // `ntile` 64-row tiles (from tile index `tile0`) of two head views -> natural LDS tiles in slots slotA.. / slotB..
+  // (rows past `nrows` are zeros).  Every global load of the call is in flight before the first LDS store: one memory
+  // round trip per call, not one per tile.
+  constexpr int PER = 64 * CPR;                     // 16-byte chunks of one tile
+  auto stage2 = [&](const T* A, int a_rs, const T* Bp, int b_rs, int tile0, int ntile, int nrows, int slotA, int slotB) {
+    uint4 v[CPR];                                   // 2 x 4 x PER / 512 chunks per thread at most
+#pragma unroll
+    for (int i = 0; i < CPR; ++i) {
+      const int c = tid + i * 512;
+      v[i] = uint4{0u, 0u, 0u, 0u};
+      if (c < 2 * ntile * PER) {
+        const int which = c >= ntile * PER ? 1 : 0;
+        const int c2 = c - which * ntile * PER;
+        const int t = c2 / PER, rem = c2 - t * PER;
+        const int row = rem / CPR, cc = rem - row * CPR;
+        const int r = (tile0 + t) * 64 + row;
+        if (r < nrows) v[i] = *reinterpret_cast<const uint4*>((which ? Bp : A) + (size_t)r * (which ? b_rs : a_rs) + cc * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CPR; ++i) {
+      const int c = tid + i * 512;
+      if (c < 2 * ntile * PER) {
+        const int which = c >= ntile * PER ? 1 : 0;
+        const int c2 = c - which * ntile * PER;
+        const int t = c2 / PER, rem = c2 - t * PER;
+        const int row = rem / CPR, cc = rem - row * CPR;
+        *reinterpret_cast<uint4*>(smem + ((which ? slotB : slotA) + t) * NAT + (cc >> 3) * (64 * 128) + lds_chunk_off(row, cc & 7)) = v[i];
+      }
+    }
+  };
+
+  // ---- phase 0 ------------------------------------------------------------------------------------------------
+  stage2(Q, p.q_rs, DO, p.o_rs, 0, nq, p.L, 0, 4);
+  {
+    // delta_self = rowsum(dO * (O - O_cross)), delta_cross = rowsum(dO * O_cross): two threads per query row; O and
+    // O_cross come from global memory (issued before the barrier), dO from the tile just staged
+    const T* Op = reinterpret_cast<const T*>(p.out) + (size_t)b * p.o_bs + (size_t)h * D;
+    const T* Ocp = p.out_cross ? reinterpret_cast<const T*>(p.out_cross) + (size_t)b * p.o_bs + (size_t)h * D : nullptr;
+    const int qi = tid >> 1, half = tid & 1;
+    float a = 0.f, c = 0.f;
+    Chunk<T> ov[CPR / 2], cv_[CPR / 2];
+    if (qi < p.L) {
+#pragma unroll
+      for (int j = 0; j < CPR / 2; ++j) {
+        const size_t off = (size_t)qi * p.o_rs + (half * (CPR / 2) + j) * 8;
+        ov[j].load(Op + off);
+        if (Ocp) cv_[j].load(Ocp + off);
+      }
+    }
+    __syncthreads();   // the staged dO tiles are visible
+    if (qi < p.L) {
+      const char* Gt = smem + (4 + (qi >> 6)) * NAT;
+#pragma unroll
+      for (int j = 0; j < CPR / 2; ++j) {
+        const int cc = half * (CPR / 2) + j;
+        Chunk<T> g;
+        g.load(reinterpret_cast<const T*>(Gt + (cc >> 3) * (64 * 128) + lds_chunk_off(qi & 63, cc & 7)));
+        const Chunk<T>& o = ov[j];
+        const Chunk<T>& oc = cv_[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float cv = Ocp ? oc.v[e] : 0.f;
+          a += g.v[e] * (o.v[e] - cv);
+          c += g.v[e] * cv;
+        }
+      }
+    }
+    a += __shfl_xor(a, 1, 64);
+    c += __shfl_xor(c, 1, 64);
+    if (half == 0) {
+      const size_t lo = ((size_t)b * p.H + h) * p.L + qi;
+      const bool ok = qi < p.L;
+      lse_self[qi] = ok ? p.lse_self[lo] * LOG2E : 1e30f;
+      lse_cross[qi] = (ok && has_c) ? p.lse_cross[lo] * LOG2E : 1e30f;
+      del_self[qi] = ok ? a : 0.f;
+      del_cross[qi] = ok ? c : 0.f;
+    }
+  }
+  // ---- phase 1: dK / dV ---------------------------------------------------------------------------------------------
+  const int nself_g = (p.L + 127) >> 7, ncross_g = has_c ? (p.S + 127) >> 7 : 0;
+  // K / V fragments of this wave's 16-key tile of group `grp` (self groups first, then the text keys); fetched one
+  // group ahead, so the global latency hides behind the previous group's MFMAs (and the first behind phase 0)
+  Frag<T> kn[DS], vn[DS];
+  auto fetch_kv = [&](int grp) {
+    const int pass = grp >= nself_g ? 1 : 0;
+    const int key = (pass ? grp - nself_g : grp) * 128 + wave * 16 + l16;
+    const bool ok = grp < nself_g + ncross_g && key < (pass ? p.S : p.L);
+    const T* Kp = reinterpret_cast<const T*>(pass ? p.kc : p.k) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
+    const T* Vp = reinterpret_cast<const T*>(pass ? p.vc : p.v) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
+    const int rs = pass ? p.c_rs : p.k_rs;
+#pragma unroll
+    for (int ks = 0; ks < DS; ++ks) {
+      frag_from_global<T>(kn[ks], ok ? Kp + (size_t)key * rs + ks * 32 + quad * 8 : Q, ok);
+      frag_from_global<T>(vn[ks], ok ? Vp + (size_t)key * rs + ks * 32 + quad * 8 : Q, ok);
+    }
+  };
+  fetch_kv(0);
+  __syncthreads();
+
+  for (int grp = 0; grp < nself_g + ncross_g; ++grp) {
+    const int pass = grp >= nself_g ? 1 : 0;
+    const int g0 = (pass ? grp - nself_g : grp) * 128 + wave * 16;
+    const int nk = pass ? p.S : p.L;
+    Frag<T> kf[DS], vf[DS];
+#pragma unroll
+    for (int ks = 0; ks < DS; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+    fetch_kv(grp + 1);
+    if (__builtin_amdgcn_readfirstlane(g0) >= nk) continue;   // wave-uniform: no real key in this wave's tile
+    const int key = g0 + l16;
+    const bool key_ok = key < nk;
+    bool key_live = key_ok;
+    if (key_ok && pass && p.mask) key_live = p.mask[(size_t)b * p.S + key] != 0.f;
+    const float* lse_a = pass ? lse_cross : lse_self;
+    const float* del_a = pass ? del_cross : del_self;
+    f32x4 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int qt = 0; qt < nq; ++qt) {
+      const char* Qs = smem + qt * NAT;
+      const char* Gs = smem + (4 + qt) * NAT;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int row = perm_row(hh * 2 + k2, l16);
+          s[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < DS; ++ks) {
+            Frag<T> a, g;
+            load_frag<T>(a, Qs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+            load_frag<T>(g, Gs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+            mma16(s[k2], a, kf[ks]);
+            mma16(dp[k2], g, vf[ks]);
+          }
+        }
+        // lane: key = l16 (column), query positions qt*64 + hh*32 + quad*8 + k2*4 + i
+        f32x4 pr[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_a + qt * 64 + hh * 32 + quad * 8 + k2 * 4);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_a + qt * 64 + hh * 32 + quad * 8 + k2 * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float pv = key_live ? __builtin_amdgcn_exp2f(fmaf(s[k2][i], c2, -l4[i])) : 0.f;
+            pr[k2][i] = pv;
+            s[k2][i] = pv * (dp[k2][i] - d4[i]);
+          }
+        }
+        Frag<T> pf, dsf;
+        frag_from_acc<T>(pf, pr[0], pr[1]);
+        frag_from_acc<T>(dsf, s[0], s[1]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          Frag<T> a, g;
+          troff.read(g, Gs, dt, hh);
+          troff.read(a, Qs, dt, hh);
+          mma16(dv[dt], g, pf);
+          mma16(dk[dt], a, dsf);
+        }
+      }
+    }
+    if (key_ok) {
+      T* DK = reinterpret_cast<T*>(pass ? p.dkc : p.dk) + (size_t)b * (pass ? p.dkc_bs : p.dk_bs) + (size_t)h * D + (size_t)key * (pass ? p.dkc_rs : p.dk_rs);
+      T* DV = reinterpret_cast<T*>(pass ? p.dvc : p.dv) + (size_t)b * (pass ? p.dkc_bs : p.dk_bs) + (size_t)h * D + (size_t)key * (pass ? p.dkc_rs : p.dk_rs);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          DK[dt * 16 + quad * 4 + i] = from_f32<T>(dk[dt][i] * p.scale);
+          DV[dt * 16 + quad * 4 + i] = from_f32<T>(dv[dt][i]);
+        }
+    }
+  }
+
+  // ---- phase 2: dQ --------------------------------------------------------------------------------------------------
+  const int nqp = (p.L + 127) >> 7;           // query passes of 128 (16 per wave)
+  f32x4 dq[2][DT];
+#pragma unroll
+  for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[qp][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Q / dO fragments of the wave's 16 queries of either pass: fetched once, before the K / V tiles are staged
+  Frag<T> qf2[2][DS], gf2[2][DS];
+#pragma unroll
+  for (int qp = 0; qp < 2; ++qp) {
+    const int qi = qp * 128 + wave * 16 + l16;
+    const bool ok = qp < nqp && qi < p.L;
+#pragma unroll
+    for (int ks = 0; ks < DS; ++ks) {
+      frag_from_global<T>(qf2[qp][ks], ok ? Q + (size_t)qi * p.q_rs + ks * 32 + quad * 8 : Q, ok);
+      frag_from_global<T>(gf2[qp][ks], ok ? DO + (size_t)qi * p.o_rs + ks * 32 + quad * 8 : DO, ok);
+    }
+  }
+  // key tiles in two groups of at most three (K in slots 0-2, V in slots 3-5): {self 0, self 1, text}, {self 2, self 3}
+  const T* Kself = reinterpret_cast<const T*>(p.k) + (size_t)b * p.k_bs + (size_t)h * D;
+  const T* Vself = reinterpret_cast<const T*>(p.v) + (size_t)b * p.k_bs + (size_t)h * D;
+  for (int grp = 0; grp < (nq > 2 ? 2 : 1); ++grp) {
+    const int ts = grp ? nq - 2 : min(nq, 2);                 // self tiles of this group
+    const int tn = ts + ((grp == 0 && has_c) ? 1 : 0);
+    __syncthreads();   // every wave is done with what the LDS held (phase 1 / the previous group)
+    stage2(Kself, p.k_rs, Vself, p.k_rs, grp * 2, ts, p.L, 0, 3);
+    if (grp == 0 && has_c) {
+      const T* Kc = reinterpret_cast<const T*>(p.kc) + (size_t)b * p.c_bs + (size_t)h * D;
+      const T* Vc = reinterpret_cast<const T*>(p.vc) + (size_t)b * p.c_bs + (size_t)h * D;
+      stage2(Kc, p.c_rs, Vc, p.c_rs, 0, 1, p.S, ts, 3 + ts);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {
+      const int q0 = qp * 128 + wave * 16;
+      if (qp >= nqp || __builtin_amdgcn_readfirstlane(q0) >= p.L) continue;
+      const int qi = q0 + l16;
+      const Frag<T>(&qf)[DS] = qf2[qp];
+      const Frag<T>(&gf)[DS] = gf2[qp];
+      for (int j = 0; j < tn; ++j) {
+        const bool cross = j >= ts;
+        const int k0 = cross ? 0 : (grp * 2 + j) * 64, nk = cross ? p.S : p.L;
+        const float* mrow = (cross && p.mask) ? p.mask + (size_t)b * p.S : nullptr;
+        const float lse = (cross ? lse_cross : lse_self)[qi & 255];
+        const float del = (cross ? del_cross : del_self)[qi & 255];
+        const char* Ks = smem + j * NAT;
+        const char* Vs = smem + (3 + j) * NAT;
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const int row = perm_row(kt, l16);
+          Frag<T> kf[DS], vf[DS];
+#pragma unroll
+          for (int ks = 0; ks < DS; ++ks) {
+            load_frag<T>(kf[ks], Ks + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+            load_frag<T>(vf[ks], Vs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+          }
+          s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < DS; ++ks) {
+            mma16(s[kt], kf[ks], qf[ks]);
+            mma16(dp[kt], vf[ks], gf[ks]);
+          }
+        }
+        if ((k0 + 64 <= nk) && !mrow) {   // full, unmasked tile (block-uniform): no per-key predicate
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][i], c2, -lse));
+              s[kt][i] = pr * (dp[kt][i] - del);
+            }
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int key = k0 + (kt >> 1) * 32 + quad * 8 + (kt & 1) * 4 + i;
+              bool ok = key < nk;
+              if (ok && mrow) ok = mrow[key] != 0.f;
+              const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[kt][i], c2, -lse)) : 0.f;
+              s[kt][i] = pr * (dp[kt][i] - del);
+            }
+        }
+        Frag<T> dsf[2];
+        frag_from_acc<T>(dsf[0], s[0], s[1]);
+        frag_from_acc<T>(dsf[1], s[2], s[3]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            Frag<T> ktf;
+            troff.read(ktf, Ks, dt, hh);
+            mma16(dq[qp][dt], ktf, dsf[hh]);
+          }
+      }
+    }
+  }
+  T* DQ = reinterpret_cast<T*>(p.dq) + (size_t)b * p.q_bs + (size_t)h * D;
+#pragma unroll
+  for (int qp = 0; qp < 2; ++qp) {
+    const int qi = qp * 128 + wave * 16 + l16;
+    if (qp >= nqp || qi >= p.L) continue;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      T* dst = DQ + (size_t)qi * p.q_rs + dt * 16 + quad * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = from_f32<T>(dq[qp][dt][i] * p.scale);
+    }
+  }
+}
+
 }  // namespace mdm
 
 using namespace mdm;
@@ -899,6 +1230,16 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
   ensure_dynamic_lds(kkv, smem_kv);
   a.delta_self_w = const_cast<float*>(a.delta_self); a.delta_cross_w = const_cast<float*>(a.delta_cross);
   a.dkc = dkc; a.dvc = dvc; a.dkc_bs = dc_bs; a.dkc_rs = dc_rs;
+  if constexpr (sizeof(T) == 2) {
+    // short sequences: one block per (batch, head), operands LDS-resident (attn_bwd_small_kernel)
+    static const bool split_only = getenv("MDM_HIP_ATTN_BWD_SPLIT") != nullptr;   // development A/B switch
+    if (a.L <= 256 && (!a.kc || a.S <= 64) && !split_only) {
+      constexpr int smem_small = 8 * G::NAT_BYTES + 4096;
+      ensure_dynamic_lds(attn_bwd_small_kernel<D>, smem_small);
+      hipLaunchKernelGGL((attn_bwd_small_kernel<D>), dim3(a.B * a.H), dim3(512), smem_small, st, a);
+      MDM_LAUNCH_STATUS();
+    }
+  }
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, DQ_QT>), dim3((a.L + 64 * DQ_QT - 1) / (64 * DQ_QT), a.B * a.H), dim3(256), smem_q, st, a);
   const int nself = (a.L + 64 * KV_KT - 1) / (64 * KV_KT), ncross = a.kc ? (a.S + 64 * KV_KT - 1) / (64 * KV_KT) : 0;
   hipLaunchKernelGGL(kkv, dim3(nself + ncross, a.B * a.H), dim3(256), smem_kv, st, a);

@@ -65,6 +65,10 @@ __device__ __forceinline__ void load4(const bf16* p, float (&o)[4]) {
 // 16-byte-aligned zeros in device memory: the source of every out-of-range LDS-DMA chunk
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[4] = {};
 
+// development knobs (include/mdm_hip_dev.h: mdm_dev_set_knob), all 0 in the product:
+//   [1] GEMM epilogues skip their global stores (what the store phase of a kernel costs; tools/kbench.py stores)
+__device__ int g_knobs[4] = {0, 0, 0, 0};
+
 // Epilogue shared by the GEMM kernels: bias / activation / residual in registers (fp32), then the finished tile is
 // staged through LDS (free after the k-loop, LDS_BYTES of it) so that HBM sees whole 16-byte chunks of complete
 // output rows instead of the 8-byte-per-lane fragments of the MFMA layout.
@@ -145,6 +149,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
       const int row = idx / OCH, ch = idx - row * OCH;
       const int m = m0 + row, n = n0 + ch * EPV;
       if (m >= p.M || n >= p.Cout) continue;
+      if (g_knobs[1]) continue;
       const size_t o = (size_t)m * p.Cout + n;
       if (act == 0 && !R) {
         *reinterpret_cast<uint4*>(Y + o) = raw[i];
@@ -1820,10 +1825,12 @@ static int launch_conv_bl_splitk(ConvArgs a, int splits, float* ws, hipStream_t 
 // (2 blocks / CU), 256x192 and 256x256 (1 block / CU); the cheapest by rounds x tile area / relative efficiency wins
 // (relative efficiencies measured with tools/kbench.py: the larger tiles move fewer LDS bytes per FLOP; N = 768 --
 // 130 GEMMs of a step -- is exactly one round of 256x192 tiles at M = 16384).
+static int g_force_tile = 0;   // development knob 2 (mdm_dev_set_knob): 128128 / 256192 / 256256, 0 = cost model
 static int conv_tile_code(int M, int Cout, int dtype) {
   if (Cout <= 32) return 128032;
   if (Cout <= 64) return 128064;
   if (dtype != DT_BF16) return 128128;
+  if (g_force_tile) return g_force_tile;
   const long mt128 = (M + 127) / 128, mt256 = (M + 255) / 256;
   const long t128 = mt128 * ((Cout + 127) / 128), t192 = mt256 * ((Cout + 191) / 192), t256 = mt256 * ((Cout + 255) / 256);
   const double c128 = (double)((t128 + 511) / 512) * 2.0 * 1.0 / 0.80;
@@ -1930,6 +1937,12 @@ extern "C" int mdm_linear_grouped(const void* const* x, const void* const* w_pac
   if (code == 256256) return launch_conv_bl_grouped<256, 256, 2, 4>(a, gr, st);
   if (code == 256192) return launch_conv_bl_grouped<256, 192, 2, 4>(a, gr, st);
   return launch_conv_bl_grouped<128, 128, 2, 2>(a, gr, st);
+}
+
+extern "C" int mdm_dev_set_knob(int idx, int value) {
+  MDM_CHECK_ARG(idx >= 0 && idx < 4);
+  if (idx == 2) g_force_tile = value;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdm::g_knobs), &value, sizeof(int), idx * sizeof(int));
 }
 
 // workspace size (bytes) the caller must provide to mdm_conv_wgrad

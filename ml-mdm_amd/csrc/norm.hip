@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ part, const float* __restrict__ stats,
                                                            const float* __restrict__ coef, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const T* __restrict__ film,
-                                                           const T* __restrict__ dres, T* __restrict__ dx,
+                                                           const T* __restrict__ dres, const T* __restrict__ dres2,
+                                                           T* __restrict__ dx,
                                                            T* __restrict__ dfilm, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int HW, int C, int G, int CB,
                                                            int slabs, int pix_per_block, int pstride) {
@@ -302,6 +303,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     if (dres) {
       Chunk<T> cr;
       cr.load(dres + off);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) cd.v[e] += cr.v[e];
+    }
+    if (dres2) {   // a second consumer of x outside the block (the U-Net's skip connection)
+      Chunk<T> cr;
+      cr.load(dres2 + off);
 #pragma unroll
       for (int e = 0; e < EPV; ++e) cd.v[e] += cr.v[e];
     }
@@ -441,6 +448,7 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ coef, T* __restrict__ dx,
                                                             T* __restrict__ dfilm, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, const T* __restrict__ dres,
+                                                            const T* __restrict__ dres2,
                                                             int HW, int C, int G, int CB, int pstride) {
   constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = NTHR / LPR, NW = NTHR / 64;
   __shared__ float sh[NW][LPR][2 * EPV];
@@ -550,6 +558,12 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
       if (dres) {   // gradient that reaches x through the residual branch: added here instead of by a separate kernel
         Chunk<T> vr;
         vr.load(dres + base + (size_t)p * C);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) vd.v[e] += vr.v[e];
+      }
+      if (dres2) {   // ... and through a second consumer of x outside the block (the U-Net's skip connection)
+        Chunk<T> vr;
+        vr.load(dres2 + base + (size_t)p * C);
 #pragma unroll
         for (int e = 0; e < EPV; ++e) vd.v[e] += vr.v[e];
       }
@@ -830,9 +844,9 @@ extern "C" int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, 
 // kernels add one term per sample with fp32 atomics; 2 = dgamma / dbeta are per-sample rows [N][C] that the kernels
 // fill with plain stores (no atomics), to be summed by mdm_gn_param_reduce_multi.
 extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* film,
-                          const float* stats, const float* coef, const void* dres, void* dx, float* dgamma,
-                          float* dbeta, void* dfilm, float* ws, int N, int HW, int C, int G, int act, int accumulate,
-                          int dtype, void* stream) {
+                          const float* stats, const float* coef, const void* dres, const void* dres2, void* dx,
+                          float* dgamma, float* dbeta, void* dfilm, float* ws, int N, int HW, int C, int G, int act,
+                          int accumulate, int dtype, void* stream) {
   MDM_CHECK_ARG(dy && x && gamma && beta && stats && coef && dx && dgamma && dbeta && ws);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
   MDM_CHECK_ARG((film == nullptr) == (dfilm == nullptr));
@@ -854,8 +868,8 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
     const int lpr = dtype == DT_F32 ? 16 : 8;
     const int nthr = HW <= 4 * (512 / lpr) ? 512 : 1024;
 #define MDM_GN_FUSED_BWD(TT, ACT)                                                                                  \
-    if (nthr == 512) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 512>), grid, dim3(512), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, dgamma, dbeta, (const TT*)dres, HW, C, G, cb, pstride); \
-    else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 1024>), grid, dim3(1024), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, dgamma, dbeta, (const TT*)dres, HW, C, G, cb, pstride)
+    if (nthr == 512) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 512>), grid, dim3(512), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, dgamma, dbeta, (const TT*)dres, (const TT*)dres2, HW, C, G, cb, pstride); \
+    else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 1024>), grid, dim3(1024), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, dgamma, dbeta, (const TT*)dres, (const TT*)dres2, HW, C, G, cb, pstride)
     if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_BWD(float, 1); } else { MDM_GN_FUSED_BWD(float, 0); } }
     else { if (act) { MDM_GN_FUSED_BWD(bf16, 1); } else { MDM_GN_FUSED_BWD(bf16, 0); } }
 #undef MDM_GN_FUSED_BWD
@@ -872,7 +886,7 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
   hipLaunchKernelGGL((gn_bwd_partial_kernel<TT, ACT>), dim3(N * slabs), dim3(256), 0, st, (const TT*)dy,             \
                      (const TT*)x, coef, ws, HW, C, slabs, pps);                                                     \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, ACT>), agrid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, ws, stats, \
-                     coef, gamma, beta, (const TT*)film, (const TT*)dres, (TT*)dx, (TT*)dfilm, dgamma, dbeta, HW, C, G,  \
+                     coef, gamma, beta, (const TT*)film, (const TT*)dres, (const TT*)dres2, (TT*)dx, (TT*)dfilm, dgamma, dbeta, HW, C, G,  \
                      cb, slabs, ppb, pstride);
   if (dtype == DT_F32) { if (act) { MDM_GN_BWD(float, 1) } else { MDM_GN_BWD(float, 0) } }
   else { if (act) { MDM_GN_BWD(bf16, 1) } else { MDM_GN_BWD(bf16, 0) } }

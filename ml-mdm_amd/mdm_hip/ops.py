@@ -751,6 +751,10 @@ class GroupNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, beta, film, stats, coef)
         ctx.groups, ctx.act = groups, act
         ctx.passthrough = passthrough
+        if passthrough == 2:
+            # third output = x once more, for a consumer OUTSIDE the block (the U-Net's skip connection): its gradient
+            # arrives as dres2 and is added in the same kernel -- no accumulation kernel of the autograd engine
+            return y, x.view_as(x), x.view_as(x)
         if passthrough:
             # second output = x itself: the caller routes the block's residual branch through it, so the gradient of
             # that branch arrives HERE (dres) and is added inside the GroupNorm backward kernel
@@ -758,10 +762,13 @@ class GroupNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy, dres=None):
+    def backward(ctx, dy, dres=None, dres2=None):
         x, gamma, beta, film, stats, coef = ctx.saved_tensors
         dy = _c(dy)
         dres = _c(dres) if dres is not None else None
+        dres2 = _c(dres2) if dres2 is not None else None
+        if dres is None and dres2 is not None:
+            dres, dres2 = dres2, None
         N, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (N * C)
         g32, b32 = _c(gamma.detach().float()), _c(beta.detach().float())
@@ -777,8 +784,9 @@ class GroupNormFn(torch.autograd.Function):
         dfilm = torch.empty_like(film) if film is not None else None
         ws = _gn_ws(N, HW, C, ctx.groups, x.device)
         mode = 2 if deferred else (1 if sunk else 0)
-        _prof_wrap("group_norm bwd (HW=%d)" % HW, (4.0 if dres is not None else 3.0) * x.numel() * x.element_size(), lambda: _lib.check(
-            _lib.lib().mdm_gn_bwd(_p(dy), _p(x), _p(g32), _p(b32), _p(film), _p(stats), _p(coef), _p(dres), _p(dx), _p(dgamma),
+        npass = 3.0 + (dres is not None) + (dres2 is not None)
+        _prof_wrap("group_norm bwd (HW=%d)" % HW, npass * x.numel() * x.element_size(), lambda: _lib.check(
+            _lib.lib().mdm_gn_bwd(_p(dy), _p(x), _p(g32), _p(b32), _p(film), _p(stats), _p(coef), _p(dres), _p(dres2), _p(dx), _p(dgamma),
                                   _p(dbeta), _p(dfilm), _p(ws), N, HW, C, ctx.groups, ctx.act, mode, _dt(x), _stream()),
             "mdm_gn_bwd",
         ), kind="hbm")
@@ -796,8 +804,9 @@ class GroupNormFn(torch.autograd.Function):
 
 def group_norm(x, gamma, beta, groups, eps=1e-5, film=None, silu=False, passthrough=False):
     """``passthrough=True`` returns ``(y, x_res)``: use ``x_res`` (== x) for the residual branch of the block this
-    norm opens, and the residual gradient is folded into the norm's backward kernel."""
-    return GroupNormFn.apply(x, gamma, beta, film, groups, eps, 1 if silu else 0, passthrough)
+    norm opens, and the residual gradient is folded into the norm's backward kernel.  ``passthrough=2`` returns
+    ``(y, x_res, x_skip)``: ``x_skip`` (== x again) is for a second consumer outside the block (a skip connection)."""
+    return GroupNormFn.apply(x, gamma, beta, film, groups, eps, 1 if silu else 0, int(passthrough))
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -92,6 +92,9 @@ def zero_module(module):
     return module
 
 
+_SKIP_TAP = os.environ.get("MDM_HIP_SKIP_TAP", "1") != "0"   # A/B switch of the skip-gradient pass-through (ResNet.forward)
+
+
 def compute_dtype() -> torch.dtype:
     """bf16 under ``torch.autocast`` (the reference's ``fp16: 1`` path, trainer.py:29-30) or
     when MDM_HIP_DTYPE=bf16; otherwise exact fp32."""
@@ -120,12 +123,18 @@ class ResNet(nn.Module):
         if cout != cin:
             self.conv3 = nn.Conv2d(cin, cout, kernel_size=1, bias=True)
 
-    def forward(self, x, temb_act):
-        """x: NHWC activation; temb_act: silu(temb) [B, T] (shared by all blocks)."""
+    def forward(self, x, temb_act, tap=None):
+        """x: NHWC activation; temb_act: silu(temb) [B, T] (shared by all blocks).  ``tap = (list, index)``: the entry
+        ``list[index]`` holds this very x as a skip activation (reference unet.py:883-897); it is replaced by a second
+        pass-through output of norm1, so that in backward the skip connection's gradient reaches x inside the
+        GroupNorm kernel instead of through an accumulation kernel of the autograd engine."""
         if self.config.dropout > 0 and self.training:
             raise NotImplementedError("dropout > 0 is not implemented on the HIP path")
         g = self.config.num_groups_norm
-        h, x = ops.group_norm(x, self.norm1.weight, self.norm1.bias, g, self.norm1.eps, silu=True, passthrough=True)
+        if tap is not None and x.requires_grad and tap[0][tap[1]] is x and _SKIP_TAP:
+            h, x, tap[0][tap[1]] = ops.group_norm(x, self.norm1.weight, self.norm1.bias, g, self.norm1.eps, silu=True, passthrough=2)
+        else:
+            h, x = ops.group_norm(x, self.norm1.weight, self.norm1.bias, g, self.norm1.eps, silu=True, passthrough=True)
         h = ops.conv(h, self.conv1.weight, self.conv1.bias)
         if isinstance(temb_act, TimeStates):
             film = temb_act.film.get(id(self))
@@ -252,20 +261,29 @@ class ResNetBlock(nn.Module):
             c = resnet_configs[-1].output_channels
             self.resample = nn.Conv2d(c, c, kernel_size=3, stride=2 if downsample_output else 1, padding=1, bias=True)
 
-    def forward(self, x, temb_act, skip_activations=None, return_activations=False, conditioning=None, cond_mask=None):
+    def forward(self, x, temb_act, skip_activations=None, return_activations=False, conditioning=None, cond_mask=None,
+                tap=None):
+        """``tap``: where the incoming x is recorded as a skip activation, if it is (see ResNet.forward)"""
         if self.level_entry:
             # backward reaches this point once every layer of this and the previous resolution level is done: queued
             # same-shape weight gradients of that level go out as grouped launches here (ops.flush_wgrad_queue)
-            x = ops.wgrad_flush_point(x)
+            if tap is not None and tap[0][tap[1]] is x:
+                x = tap[0][tap[1]] = ops.wgrad_flush_point(x)
+            else:
+                x = ops.wgrad_flush_point(x)
         activations = []
         L = self.num_attention_layers
         for i in range(self.num_residual_blocks):
             if skip_activations is not None:
                 x = ops.concat(x, skip_activations.pop(0))
-            x = self.resnets[i](x, temb_act)
+                tap = None
+            x = self.resnets[i](x, temb_act, tap)
+            tap = None
             for j in range(L):
                 x = self.attn[i * L + j](x, conditioning, cond_mask)
             activations.append(x)
+            if skip_activations is None:
+                tap = (activations, len(activations) - 1)   # the next ResNet of this block reads the x recorded here
         if self.downsample_output:
             x = ops.conv(x, self.resample.weight, self.resample.bias, stride=2)
             activations.append(x)
@@ -486,10 +504,11 @@ class UNet(nn.Module):
     def forward_downsample(self, x, temb_act, conditioning, cond_mask):
         skips = [x]
         for i, block in enumerate(self.down_blocks):
+            tap = (skips, len(skips) - 1)   # the x this block starts from is the last recorded skip activation
             if i in self.config.attention_levels:
-                x, acts = block(x, temb_act, return_activations=True, conditioning=conditioning, cond_mask=cond_mask)
+                x, acts = block(x, temb_act, return_activations=True, conditioning=conditioning, cond_mask=cond_mask, tap=tap)
             else:
-                x, acts = block(x, temb_act, return_activations=True)
+                x, acts = block(x, temb_act, return_activations=True, tap=tap)
             skips.extend(acts)
         return x, skips
 
@@ -517,7 +536,7 @@ class UNet(nn.Module):
             x = ops.add(x, x_feat)
         x, skips = self.forward_downsample(x, temb_act, conditioning, cond_mask)
         if not self.config.skip_mid_blocks:
-            x = self.mid_blocks[0](x, temb_act, conditioning=conditioning, cond_mask=cond_mask)
+            x = self.mid_blocks[0](x, temb_act, conditioning=conditioning, cond_mask=cond_mask, tap=(skips, len(skips) - 1))
             x = self.mid_blocks[1](x, temb_act)
         x = self.forward_upsample(x, temb_act, conditioning, cond_mask, skips)
         x_out = self.forward_output_layer(x)

@@ -447,7 +447,13 @@ def reference_bf16_error():
         ref.load_state_dict(sd, strict=True)
         return ref
 
+    only = [a for a in sys.argv[2:] if a in PC.CASES or a in PC.FULL]
+    path = os.path.join(ROOT, "tests", "golden", "reference_bf16_error.pt")
+    if only:
+        res = torch.load(path)
     for name in PC.CASES:
+        if only and name not in only:
+            continue
         _, cfg, sd = PC.build_module(name)
         ref, inp = build(cfg, sd), PC.inputs(name)
         o32 = PC.as_list(ref(inp["x"], inp["times"], inp["cond"], inp["mask"]))
@@ -463,6 +469,8 @@ def reference_bf16_error():
         print(name, res[name], flush=True)
     gold = torch.load(os.path.join(ROOT, "tests", "golden", "full_size.pt"), weights_only=False)
     for name in PC.FULL:
+        if only and name not in only:
+            continue
         _, sd = PC.full_module(name)
         ref, inp = build(PC.full_cfg(name), sd), PC.full_inputs(name)
         with_grad = "grad_norm" in gold[name]
@@ -478,7 +486,7 @@ def reference_bf16_error():
                       for k, p in ref.named_parameters())
             res[name]["grad_agg"] = (num / sum(n * n for n in g["grad_norm"].values())) ** 0.5
         print(name, res[name], flush=True)
-    torch.save(res, os.path.join(ROOT, "tests", "golden", "reference_bf16_error.pt"))
+    torch.save(res, path)
 
 
 if __name__ == "__main__":

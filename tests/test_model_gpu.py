@@ -301,11 +301,21 @@ def test_full_size_architectures_match_reference(which):
         grads = {k: p.grad for k, p in model.named_parameters()}
         norms = sorted(gold["grad_norm"].values())
         floor = 1e-2 * norms[len(norms) // 2]
+        bad = []
         for k, n in gold["grad_norm"].items():
             gk = grads[k].double().cpu()
-            assert abs(float(gk.norm()) - n) <= 2e-3 * max(n, floor), k
+            mine = float(gk.norm())
             probe = float((gk * PC.probe_for(k, gk.shape)).sum())
-            assert abs(probe - gold["grad_probe"][k]) <= 8e-3 * max(n, floor), k
+            if n < 0.1 * floor:
+                # a gradient that is mathematically zero (bias of a conv in front of a 1-channel-per-group GroupNorm: the
+                # outer 32-channel levels of the 1024 net) is rounding noise of a sum over up to 10^6 pixels on BOTH
+                # sides; the two noises need not agree, they only have to be negligible: < 0.5 % of the median norm
+                ok = mine <= 0.5 * floor
+            else:
+                ok = abs(mine - n) <= 2e-3 * max(n, floor) and abs(probe - gold["grad_probe"][k]) <= 8e-3 * max(n, floor)
+            if not ok:
+                bad.append((k, mine, n, probe, gold["grad_probe"][k]))
+        assert not bad, (floor, bad[:8])
         agg32 = _agg_grad_err(grads, gold)
         model.zero_grad(set_to_none=True)
     # bf16 mode on the same input

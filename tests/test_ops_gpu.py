@@ -262,6 +262,34 @@ def test_group_norm_residual_passthrough(dtype, N, HW, C, G):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,HW,C,G", [(2, 256, 768, 32), (2, 1024, 512, 32), (2, 4096, 256, 32)])
+def test_group_norm_two_passthroughs(dtype, N, HW, C, G):
+    """x is also a skip activation: a third output carries it to a consumer outside the block, and BOTH extra gradients
+    (residual branch, skip connection) are added inside the GroupNorm backward kernel (mdm_gn_bwd dres / dres2;
+    single-kernel and two-kernel paths) -- what the autograd engine did with one accumulation kernel per skip."""
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(6)
+    H = int(math.isqrt(HW)); W = HW // H
+    x = q(torch.randn(N, C, H, W, generator=g), dtype).requires_grad_()
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_()
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_()
+    w_res, w_skip = q(torch.randn(N, C, H, W, generator=g), dtype), q(torch.randn(N, C, H, W, generator=g), dtype)
+    y_ref = F.silu(F.group_norm(x, G, gamma, beta, 1e-5)) * 1.5 + x * w_res + (x * w_skip).tanh()
+    gy = q(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+    xd = nhwc(x.detach(), dtype).requires_grad_()
+    gd, bd = gamma.detach().to(dev()).requires_grad_(), beta.detach().to(dev()).requires_grad_()
+    y, xr, xs = ops.group_norm(xd, gd, bd, G, 1e-5, silu=True, passthrough=2)
+    out = y.float() * 1.5 + xr.float() * nhwc(w_res, dtype).float() + (xs.float() * nhwc(w_skip, dtype).float()).tanh()
+    out.backward(nhwc(gy, dtype).float())
+    tol = TOL[dtype]
+    assert relerr(nchw(out), y_ref) < tol
+    assert relerr(nchw(xd.grad), x.grad) < tol
+    assert relerr(gd.grad, gamma.grad) < tol and relerr(bd.grad, beta.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_layer_norm(dtype):
     from mdm_hip import ops
 
@@ -303,6 +331,11 @@ def _attn_ref(qkv, kvc, mask, heads):
     (1, 1024, 32, 8, 64, True),       # UNet-64 level 1 geometry, masked text
     (2, 200, 77, 2, 64, True),        # ragged L and S (two key tiles for the text)
     (2, 128, 0, 4, 32, False),        # no cross attention
+    # short sequences take the one-block-per-head backward (attn_bwd_small_kernel: L <= 256, S <= 64, bf16)
+    (3, 256, 32, 8, 64, True),        # masked text, 4 query / key tiles
+    (2, 200, 20, 4, 96, True),        # ragged L (last tile partial), ragged S
+    (2, 72, 64, 2, 128, False),       # d = 128, a full text tile, L barely over one tile
+    (2, 136, 0, 2, 96, False),        # no cross attention, second 128-key / 128-query pass partial
 ])
 def test_attention(dtype, B, L, S, H, d, masked):
     from mdm_hip import ops

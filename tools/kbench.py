@@ -84,6 +84,30 @@ def main():
             t = timeit(lambda: ops._wgrad_launch(x, y, B, H, H, cin, Ho, Ho, cout, ks, stride))
             line += "  wgrad %7.3f ms %7.1f TF" % (t * 1e3, flops / t / 1e12)
         print(line, flush=True)
+    if what in ("stores",):
+        # what the store phase of the 1x1 GEMMs costs: the same launch with the epilogue's global stores skipped (dev knob 1)
+        from mdm_hip import _lib
+        L = _lib.lib()
+        for idx, (name, H, cin, cout, ks, stride) in enumerate(SHAPES):
+            if ks != 1:
+                continue
+            for act in (0, 1):
+                if act == 1 and cout < cin * 2:
+                    continue
+                x = torch.randn(B, H, H, cin, device=dev).to(DT)
+                w = (torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5)
+                wf, wd, bp, cin_p, cout_p, kbf, kbd = ops.packed_weight(w, torch.randn(cout, device=dev), DT)
+                y = torch.empty(B, H, H, cout, device=dev, dtype=DT)
+                ypre = torch.empty_like(y) if act == 1 else None
+                flops = 2.0 * B * H * H * cout * cin
+                line = "%-20s act=%d tile=%d " % (name, act, L.mdm_conv_fwd_tile(B * H * H, cout, 1))
+                for tile in (0, 128128):
+                    for knob1 in (0, 1):
+                        L.mdm_dev_set_knob(2, tile); L.mdm_dev_set_knob(1, knob1)
+                        t = timeit(lambda: ops._conv_launch(x, wf, bp, None, None, y, ypre, B, H, H, cin, H, H, cout, 1, 1, 0, act, kbf), iters=20)
+                        line += " | %s %s %6.1f us %5.0f TF" % ("128x128" if tile else "model  ", "nostore" if knob1 else "store  ", t * 1e6, flops / t / 1e12)
+                L.mdm_dev_set_knob(2, 0); L.mdm_dev_set_knob(1, 0)
+                print(line, flush=True)
     if what in ("grouped",):
         G = int(os.environ.get("KB_GROUPS", "26"))
         for name, H, cin, cout, ks, stride in SHAPES:
@@ -169,7 +193,7 @@ def main():
             gmode = int(os.environ.get('KB_GN_MODE', '2'))   # 2: per-sample rows (deferred reduce), 1: atomics into a slot
             dxx = torch.empty_like(xd); dg = torch.zeros(B if gmode == 2 else 1, C, device=dev); db = torch.zeros_like(dg)
             def direct():
-                _lib.check(_lib.lib().mdm_gn_bwd(ops._p(gy), ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(stats), ops._p(coef), None, ops._p(dxx), ops._p(dg), ops._p(db), None, ops._p(ws), B, H * H, C, 32, 1, gmode, ops._dt(xd), ops._stream()), "bwd")
+                _lib.check(_lib.lib().mdm_gn_bwd(ops._p(gy), ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(stats), ops._p(coef), None, None, ops._p(dxx), ops._p(dg), ops._p(db), None, ops._p(ws), B, H * H, C, 32, 1, gmode, ops._dt(xd), ops._stream()), "bwd")
             def directf():
                 _lib.check(_lib.lib().mdm_gn_fwd(ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(yy), ops._p(stats), ops._p(coef), ops._p(ws), B, H * H, C, 32, 1e-5, 1, ops._dt(xd), ops._stream()), "fwd")
             for f in (direct, directf):
