@@ -986,99 +986,111 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
     }
   }
   // ---- phase 1: dK / dV ---------------------------------------------------------------------------------------------
-  const int nself_g = (p.L + 127) >> 7, ncross_g = has_c ? (p.S + 127) >> 7 : 0;
-  // K / V fragments of this wave's 16-key tile of group `grp` (self groups first, then the text keys); fetched one
-  // group ahead, so the global latency hides behind the previous group's MFMAs (and the first behind phase 0)
-  Frag<T> kn[DS], vn[DS];
-  auto fetch_kv = [&](int grp) {
+  // KT = 16-key tiles per wave (as in attn_bwd_dkv_kernel): with 2, one pass covers 256 self keys, every Q / dO fragment
+  // read from LDS feeds two MFMAs and a wave has two independent MFMA chains in flight
+  constexpr int KT = D <= 64 ? 2 : 1;          // (at d = 96 two tiles spill: 166 us against 158 at L = 256, batch 64)
+  constexpr int GK = 128 * KT;                      // keys per pass over the query tiles
+  const int nself_g = (p.L + GK - 1) / GK, ncross_g = has_c ? (p.S + GK - 1) / GK : 0;
+  __syncthreads();
+  for (int grp = 0; grp < nself_g + ncross_g; ++grp) {
     const int pass = grp >= nself_g ? 1 : 0;
-    const int key = (pass ? grp - nself_g : grp) * 128 + wave * 16 + l16;
-    const bool ok = grp < nself_g + ncross_g && key < (pass ? p.S : p.L);
+    const int g0 = (pass ? grp - nself_g : grp) * GK + wave * (16 * KT);
+    const int nk = pass ? p.S : p.L;
+    if (__builtin_amdgcn_readfirstlane(g0) >= nk) continue;   // wave-uniform: no real key in this wave's tiles
     const T* Kp = reinterpret_cast<const T*>(pass ? p.kc : p.k) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
     const T* Vp = reinterpret_cast<const T*>(pass ? p.vc : p.v) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
     const int rs = pass ? p.c_rs : p.k_rs;
+    int key[KT];
+    bool key_ok[KT], key_live[KT], tile_live[KT];
+    Frag<T> kf[KT][DS], vf[KT][DS];
 #pragma unroll
-    for (int ks = 0; ks < DS; ++ks) {
-      frag_from_global<T>(kn[ks], ok ? Kp + (size_t)key * rs + ks * 32 + quad * 8 : Q, ok);
-      frag_from_global<T>(vn[ks], ok ? Vp + (size_t)key * rs + ks * 32 + quad * 8 : Q, ok);
+    for (int kk = 0; kk < KT; ++kk) {
+      key[kk] = g0 + kk * 16 + l16;
+      key_ok[kk] = key[kk] < nk;
+      tile_live[kk] = __builtin_amdgcn_readfirstlane(g0 + kk * 16) < nk;
+#pragma unroll
+      for (int ks = 0; ks < DS; ++ks) {
+        frag_from_global<T>(kf[kk][ks], Kp + (size_t)(key_ok[kk] ? key[kk] : 0) * rs + ks * 32 + quad * 8, key_ok[kk]);
+        frag_from_global<T>(vf[kk][ks], Vp + (size_t)(key_ok[kk] ? key[kk] : 0) * rs + ks * 32 + quad * 8, key_ok[kk]);
+      }
+      key_live[kk] = key_ok[kk];
+      if (key_ok[kk] && pass && p.mask) key_live[kk] = p.mask[(size_t)b * p.S + key[kk]] != 0.f;
     }
-  };
-  fetch_kv(0);
-  __syncthreads();
-
-  for (int grp = 0; grp < nself_g + ncross_g; ++grp) {
-    const int pass = grp >= nself_g ? 1 : 0;
-    const int g0 = (pass ? grp - nself_g : grp) * 128 + wave * 16;
-    const int nk = pass ? p.S : p.L;
-    Frag<T> kf[DS], vf[DS];
-#pragma unroll
-    for (int ks = 0; ks < DS; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
-    fetch_kv(grp + 1);
-    if (__builtin_amdgcn_readfirstlane(g0) >= nk) continue;   // wave-uniform: no real key in this wave's tile
-    const int key = g0 + l16;
-    const bool key_ok = key < nk;
-    bool key_live = key_ok;
-    if (key_ok && pass && p.mask) key_live = p.mask[(size_t)b * p.S + key] != 0.f;
     const float* lse_a = pass ? lse_cross : lse_self;
     const float* del_a = pass ? del_cross : del_self;
-    f32x4 dk[DT], dv[DT];
+    f32x4 dk[KT][DT], dv[KT][DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int kk = 0; kk < KT; ++kk)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { dk[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int qt = 0; qt < nq; ++qt) {
       const char* Qs = smem + qt * NAT;
       const char* Gs = smem + (4 + qt) * NAT;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        f32x4 s[2], dp[2];
+        f32x4 s[KT][2], dp[KT][2];
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
           const int row = perm_row(hh * 2 + k2, l16);
-          s[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
-          dp[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < KT; ++kk) { s[kk][k2] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kk][k2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
           for (int ks = 0; ks < DS; ++ks) {
             Frag<T> a, g;
             load_frag<T>(a, Qs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
             load_frag<T>(g, Gs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
-            mma16(s[k2], a, kf[ks]);
-            mma16(dp[k2], g, vf[ks]);
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk)
+              if (tile_live[kk]) {
+                mma16(s[kk][k2], a, kf[kk][ks]);
+                mma16(dp[kk][k2], g, vf[kk][ks]);
+              }
           }
         }
         // lane: key = l16 (column), query positions qt*64 + hh*32 + quad*8 + k2*4 + i
-        f32x4 pr[2];
+        Frag<T> pf[KT], dsf[KT];
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_a + qt * 64 + hh * 32 + quad * 8 + k2 * 4);
-          const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_a + qt * 64 + hh * 32 + quad * 8 + k2 * 4);
+        for (int kk = 0; kk < KT; ++kk) {
+          f32x4 pr[2];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float pv = key_live ? __builtin_amdgcn_exp2f(fmaf(s[k2][i], c2, -l4[i])) : 0.f;
-            pr[k2][i] = pv;
-            s[k2][i] = pv * (dp[k2][i] - d4[i]);
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_a + qt * 64 + hh * 32 + quad * 8 + k2 * 4);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_a + qt * 64 + hh * 32 + quad * 8 + k2 * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float pv = key_live[kk] ? __builtin_amdgcn_exp2f(fmaf(s[kk][k2][i], c2, -l4[i])) : 0.f;
+              pr[k2][i] = pv;
+              s[kk][k2][i] = pv * (dp[kk][k2][i] - d4[i]);
+            }
           }
+          frag_from_acc<T>(pf[kk], pr[0], pr[1]);
+          frag_from_acc<T>(dsf[kk], s[kk][0], s[kk][1]);
         }
-        Frag<T> pf, dsf;
-        frag_from_acc<T>(pf, pr[0], pr[1]);
-        frag_from_acc<T>(dsf, s[0], s[1]);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           Frag<T> a, g;
           troff.read(g, Gs, dt, hh);
           troff.read(a, Qs, dt, hh);
-          mma16(dv[dt], g, pf);
-          mma16(dk[dt], a, dsf);
+#pragma unroll
+          for (int kk = 0; kk < KT; ++kk)
+            if (tile_live[kk]) {
+              mma16(dv[kk][dt], g, pf[kk]);
+              mma16(dk[kk][dt], a, dsf[kk]);
+            }
         }
       }
     }
-    if (key_ok) {
-      T* DK = reinterpret_cast<T*>(pass ? p.dkc : p.dk) + (size_t)b * (pass ? p.dkc_bs : p.dk_bs) + (size_t)h * D + (size_t)key * (pass ? p.dkc_rs : p.dk_rs);
-      T* DV = reinterpret_cast<T*>(pass ? p.dvc : p.dv) + (size_t)b * (pass ? p.dkc_bs : p.dk_bs) + (size_t)h * D + (size_t)key * (pass ? p.dkc_rs : p.dk_rs);
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+      if (!key_ok[kk]) continue;
+      T* DK = reinterpret_cast<T*>(pass ? p.dkc : p.dk) + (size_t)b * (pass ? p.dkc_bs : p.dk_bs) + (size_t)h * D + (size_t)key[kk] * (pass ? p.dkc_rs : p.dk_rs);
+      T* DV = reinterpret_cast<T*>(pass ? p.dvc : p.dv) + (size_t)b * (pass ? p.dkc_bs : p.dk_bs) + (size_t)h * D + (size_t)key[kk] * (pass ? p.dkc_rs : p.dk_rs);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          DK[dt * 16 + quad * 4 + i] = from_f32<T>(dk[dt][i] * p.scale);
-          DV[dt * 16 + quad * 4 + i] = from_f32<T>(dv[dt][i]);
+          DK[dt * 16 + quad * 4 + i] = from_f32<T>(dk[kk][dt][i] * p.scale);
+          DV[dt * 16 + quad * 4 + i] = from_f32<T>(dv[kk][dt][i]);
         }
     }
   }
