@@ -15,7 +15,8 @@ _ROOT = os.path.dirname(os.path.dirname(_HERE))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 HEADER = os.path.join(_ROOT, "include", "mdm_hip.h")            # the drop-in boundary
 DEV_HEADER = os.path.join(_ROOT, "include", "mdm_hip_dev.h")    # profiling aids (bench.py, tools/)
-LIB_PATH = os.path.join(_HERE, "libmdm_hip.so")
+# MDM_HIP_LIB: load another build of the library (development: in-call A/B of two kernel versions on one GPU box)
+LIB_PATH = os.environ.get("MDM_HIP_LIB") or os.path.join(_HERE, "libmdm_hip.so")
 SOURCES = ["gemm_conv.hip", "norm.hip", "attention.hip", "elementwise.hip", "optim.hip", "diffusion_ops.hip"]
 
 ABI_VERSION = int(re.search(r"#define\s+MDM_HIP_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))

@@ -84,6 +84,36 @@ def main():
             t = timeit(lambda: ops._wgrad_launch(x, y, B, H, H, cin, Ho, Ho, cout, ks, stride))
             line += "  wgrad %7.3f ms %7.1f TF" % (t * 1e3, flops / t / 1e12)
         print(line, flush=True)
+    if what in ("rotate",):
+        # the store-heavy 1x1 GEMMs with FRESH output buffers every launch (a ring of `KB_RING` buffers larger than the
+        # 256 MB Infinity Cache), as in a train step -- rewriting one buffer lets the caches absorb the writes
+        ring = int(os.environ.get("KB_RING", "6"))
+        for idx, (name, H, cin, cout, ks, stride) in enumerate(SHAPES):
+            if ks != 1:
+                continue
+            for act in (0, 1, 2, 3):   # 3 = no activation, + residual
+                if act in (1, 2) and cout < cin * 2:
+                    continue
+                x = torch.randn(B, H, H, cin, device=dev).to(DT)
+                w = (torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5)
+                wf, wd, bp, cin_p, cout_p, kbf, kbd = ops.packed_weight(w, torch.randn(cout, device=dev), DT)
+                ys = [torch.empty(B, H, H, cout, device=dev, dtype=DT) for _ in range(ring)]
+                yps = [torch.empty(B, H, H, cout, device=dev, dtype=DT) for _ in range(ring)] if act == 1 else [None] * ring
+                auxs = [torch.randn(B, H, H, cout, device=dev).to(DT) for _ in range(ring)] if act >= 2 else [None] * ring
+                flops = 2.0 * B * H * H * cout * cin
+                it = [0]
+                def one():
+                    j = it[0] % ring; it[0] += 1
+                    if act == 3:
+                        ops._conv_launch(x, wf, bp, auxs[j], None, ys[j], None, B, H, H, cin, H, H, cout, 1, 1, 0, 0, kbf)
+                    else:
+                        ops._conv_launch(x, wf, bp if act != 2 else None, None, auxs[j], ys[j], yps[j], B, H, H, cin, H, H, cout, 1, 1, 0, act, kbf)
+                t = timeit(one, iters=3 * ring)
+                it[0] = 0
+                t1 = timeit(lambda: (it.__setitem__(0, 0), one())[1], iters=3 * ring)
+                out_mb = ys[0].numel() * 2 * (2 if act == 1 else 1) / 1e6
+                print("%-20s act=%d out %6.0f MB  fresh buffers %7.1f us %6.0f TF | same buffer %7.1f us %6.0f TF" % (
+                    name, act, out_mb, t * 1e6, flops / t / 1e12, t1 * 1e6, flops / t1 / 1e12), flush=True)
     if what in ("stores",):
         # what the store phase of the 1x1 GEMMs costs: the same launch with the epilogue's global stores skipped (dev knob 1)
         from mdm_hip import _lib
