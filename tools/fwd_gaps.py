@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""From a rocprofv3 (rocpd) database of bench.py: for each train step, the forward window (end of the weight re-pack of
+the previous step -> the loss-backward kernel) and the backward window: wall time, sum of kernel durations per stream,
+idle gaps on the main stream.   python tools/fwd_gaps.py <results.db>"""
+import sqlite3
+import sys
+
+c = sqlite3.connect(sys.argv[1])
+cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+rows = c.execute("select name, start, end%s from kernels order by start" % (", " + qcol if qcol else "")).fetchall()
+packs = [i for i, r in enumerate(rows) if "pack_weights_multi" in r[0]]
+for a, b in zip(packs[:-1], packs[1:]):
+    seg = rows[a + 1:b + 1]
+    lb = next((i for i, r in enumerate(seg) if "loss_bwd_kernel" in r[0]), None)
+    if lb is None:
+        continue
+    for tag, part in (("forward", seg[:lb]), ("backward+opt", seg[lb:])):
+        if not part:
+            continue
+        wall = (max(r[2] for r in part) - part[0][1]) / 1e6
+        ksum = sum(r[2] - r[1] for r in part) / 1e6
+        # union of busy intervals (any stream)
+        busy, cur_s, cur_e = 0, None, None
+        for r in sorted(part, key=lambda r: r[1]):
+            if cur_e is None or r[1] > cur_e:
+                if cur_e is not None:
+                    busy += cur_e - cur_s
+                cur_s, cur_e = r[1], r[2]
+            else:
+                cur_e = max(cur_e, r[2])
+        busy += cur_e - cur_s
+        print("%-13s %4d kernels  wall %7.2f ms  sum of kernel durations %7.2f ms  GPU busy (union) %7.2f ms  idle %5.2f ms" % (
+            tag, len(part), wall, ksum, busy / 1e6, wall - busy / 1e6))
+    print()
