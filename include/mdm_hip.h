@@ -82,6 +82,15 @@ int mdm_conv_fwd_plan(int M, int Cout, int K, int dtype, int* splits, size_t* ws
 int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float* bias, const void* res, const void* aux, void* y,
                     void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride,
                     int transposed, int act, int kblock, int dtype, float* ws, size_t ws_bytes, void* stream);
+/* mdm_conv_s2_dgrad + mdm_depth_to_space2x (ABI 3): input gradient of a STRIDE-2 3x3 convolution (pad 1, even H, W;
+ *   bf16) -- replaces the backward of the downsampling conv (models/unet.py:514-522).  dx[2b + p] only draws from
+ *   dy[b] and dy[b + 1], so over the 2x2-blocked dx it is a 2x2 stride-1 correlation: dxb [N, Ho, Wo, 4 Cin] (channel
+ *   (ph, pw, ci)) from dy [N, Ho, Wo, Cout] and w_sel [4 Cin][Cout / 64][4][64] (tap j = 2 dh + dw; zeros where a
+ *   (phase, offset) pair has no tap); mdm_depth_to_space2x then writes dx [N, 2 Ho, 2 Wo, Cin].  2.25x fewer
+ *   multiply-adds than the zero-upsampled 3x3 form of mdm_conv_fwd(transposed = 1), which stays for fp32 / odd sizes. */
+int mdm_conv_s2_dgrad(const void* dy, const void* w_sel, void* dxb, int N, int Ho, int Wo, int Cout, int Cin, int dtype,
+                      void* stream);
+int mdm_depth_to_space2x(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
 int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes);
 int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, float* ws, int N, int H, int W, int Cin, int Ho,
                    int Wo, int Cout, int ksize, int stride, int dtype, void* stream);

@@ -399,12 +399,17 @@ struct ConvGroup {
 };
 struct NoConvGroup {};
 
-template <int BM, int BN, int WM, int WN, int MODE, bool GROUPED = false, bool SPLITK = false>
+// SEL4 (3x3 only): the reduction walks only the four taps (kh, kw) in {1, 2}^2 -- pixel offsets {0, +1} -- of every
+// channel block: k-tile kt = (channel block kt >> 2, tap 4 + (kt & 1) + 3 * ((kt >> 1) & 1)), K = 4 * Cin.  That is the
+// input gradient of a STRIDE-2 3x3 convolution in its pixel-unshuffled form (mdm_conv_s2_dgrad): dx[2b + p] only draws
+// from dy[b] and dy[b + 1], so over the 2x2-blocked dx (4 Cin channels per block) it is a 2x2 stride-1 correlation.
+template <int BM, int BN, int WM, int WN, int MODE, bool GROUPED = false, bool SPLITK = false, bool SEL4 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs p, std::conditional_t<GROUPED, ConvGroup, NoConvGroup> gr) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type has no host-side counterpart: the host pass only needs the stub
   using T = bf16;
   static_assert(!GROUPED || MODE == MODE_1x1, "grouped launches: 1x1 / linear only");
   static_assert(!(GROUPED && SPLITK), "split-K launches are single problems");
+  static_assert(!SEL4 || (MODE == MODE_3x3 && !GROUPED && !SPLITK), "tap selection: plain 3x3 launches only");
   constexpr int NT_ = WM * WN * 64;
   constexpr int RPP = NT_ / 8;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -494,7 +499,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   const int b_soff = kta_ * 128;                                                                            \
   int a_soff = b_soff, tapbit = 1;                                                                          \
   if (MODE == MODE_3x3) {                                                                                   \
-    const int cb = kta_ / 9, tap = kta_ - 9 * cb;                                                           \
+    const int cb = SEL4 ? kta_ >> 2 : kta_ / 9;                                                             \
+    const int tap = SEL4 ? 4 + (kta_ & 1) + 3 * ((kta_ >> 1) & 1) : kta_ - 9 * cb;                          \
     const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;                                                      \
     a_soff = (kh * p.W + kw) * p.Cin * 2 + cb * 128;                                                        \
     tapbit = 1 << tap;                                                                                      \
@@ -1775,6 +1781,18 @@ static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
 }
 
 template <int BM, int BN, int WM, int WN>
+static int launch_conv_bl_sel4(const ConvArgs& a, hipStream_t st) {
+  constexpr int smem = 2 * (BM + BN) * 128;
+  auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE_3x3, false, false, true>;
+  ensure_dynamic_lds(kern, smem);
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+  const int resident = device_cus() * (WM * WN == 4 ? 2 : 1);
+  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a, NoConvGroup{});
+  MDM_NOTE_KERNEL("conv_gemm_bl_kernel<%d, %d, %d, %d, %d, sel4>", BM, BN, WM, WN, MODE_3x3);
+  MDM_LAUNCH_STATUS();
+}
+
+template <int BM, int BN, int WM, int WN>
 static int launch_conv_bl_grouped(const ConvArgs& a, const ConvGroup& gr, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE_1x1, true>;
@@ -1932,6 +1950,28 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
                          kblock, dtype, nullptr, 0, stream);
 }
 
+
+// Input gradient of a stride-2 3x3 convolution (pad 1, even H and W) in pixel-unshuffled form, bf16:
+//   dxb [N, Ho, Wo, 4 Cin] with channel (ph, pw, ci) = dx[n, 2 bh + ph, 2 bw + pw, ci]
+//       = sum over (dh, dw) in {0, 1}^2, co of dy[n, bh + dh, bw + dw, co] * w_sel[(ph, pw, ci)][(dh, dw)][co]
+// w_sel: [4 Cin][Cout / 64][4 taps][64] (channel-block-major, tap j = 2 dh + dw), zero where the (phase, offset) pair has
+// no tap of the 3x3 kernel (7 of 16).  2.25x fewer multiply-adds than the zero-upsampled 3x3 formulation and the
+// buffer-addressed k-loop; mdm_depth_to_space2x turns dxb into dx.  Cout % 64 == 0, Cin % 2 == 0.
+extern "C" int mdm_conv_s2_dgrad(const void* dy, const void* w_sel, void* dxb, int N, int Ho, int Wo, int Cout, int Cin,
+                                 int dtype, void* stream) {
+  MDM_CHECK_ARG(dy && w_sel && dxb && dtype == DT_BF16);
+  MDM_CHECK_ARG(N > 0 && Ho > 0 && Wo > 0 && Cout % 64 == 0 && Cin > 0 && (4 * Cin) % 8 == 0);
+  ConvArgs a = {};
+  a.x = dy; a.w = w_sel; a.y = dxb;
+  a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Ho = Ho; a.Wo = Wo; a.Cout = 4 * Cin; a.stride = 1;
+  a.M = N * Ho * Wo; a.K = 4 * Cout; a.act = 0; a.groups = 0; a.kblk = 64; a.ksplit = 1;
+  MDM_CHECK_ARG((conv_bl_ok<bf16, MODE_3x3>(a)));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int code = conv_tile_code(a.M, a.Cout, DT_BF16);
+  if (code == 256256) return launch_conv_bl_sel4<256, 256, 2, 4>(a, st);
+  if (code == 256192) return launch_conv_bl_sel4<256, 192, 2, 4>(a, st);
+  return launch_conv_bl_sel4<128, 128, 2, 2>(a, st);
+}
 
 // y[g] [M, Cout] = x[g] [M, Cin] * w_packed[g]^T + bias[g] for `groups` (<= 32) linear layers of one shape, bf16, in ONE
 // launch.  The pointer arrays are HOST arrays of device pointers; bias may be NULL (no bias at all) .  Passing the

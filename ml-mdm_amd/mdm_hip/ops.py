@@ -386,6 +386,26 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
     return val
 
 
+def packed_s2_dgrad_weight(weight: torch.Tensor):
+    """The stride-2 3x3 convolution's weight (Cout, Cin, 3, 3) in the layout of mdm_conv_s2_dgrad: bf16
+    [(ph, pw, ci)][co / 64][tap j = 2 dh + dw][co % 64], where dx[2b + p] += dy[b + d] * W[kh(p, d)]:
+    (p, d) -> kh = (0, 0) -> 1, (1, 0) -> 2, (1, 1) -> 0 (no tap for (0, 1)).  Cached per parameter version."""
+    ent = _cache_slot(weight)
+    ver = (weight._version, weight.data_ptr(), _pack_epoch)
+    if "s2dgrad" in ent and ent["s2dgrad"][0] == ver:
+        return ent["s2dgrad"][1]
+    cout, cin = weight.shape[0], weight.shape[1]
+    w = weight.detach().float()
+    sel = w.new_zeros(2, 2, cin, 2, 2, cout)            # [ph, pw, ci, dh, dw, co]
+    pairs = ((0, 0, 1), (1, 0, 2), (1, 1, 0))           # (phase, offset, kernel tap)
+    for ph, dh, kh in pairs:
+        for pw, dw, kw in pairs:
+            sel[ph, pw, :, dh, dw, :] = w[:, :, kh, kw].t()
+    packed = sel.reshape(4 * cin, 4, cout // 64, 64).permute(0, 2, 1, 3).contiguous().to(torch.bfloat16)
+    ent["s2dgrad"] = (ver, packed)
+    return packed
+
+
 _multi_tables = {}   # dtype -> (signature, device table, n, total blocks)
 
 
@@ -623,7 +643,16 @@ class ConvFn(torch.autograd.Function):
             if wd is None:
                 raise _lib.MdmHipError("input gradient requested for a channel-padded convolution")
             dx = torch.empty_like(x)
-            if ks == 3 and stride == 2:
+            if ks == 3 and stride == 2 and x.dtype == torch.bfloat16 and cout_pad == cout and cout % 64 == 0 and cin % 2 == 0 \
+                    and H % 2 == 0 and W % 2 == 0:
+                # the pixel-unshuffled form: a 2x2 correlation over dy producing 4 Cin channels per 2x2 block of dx
+                wsel = packed_s2_dgrad_weight(weight)
+                dxb = torch.empty((N, Ho, Wo, 4 * cin), dtype=x.dtype, device=x.device)
+                _prof_wrap("conv_gemm_bl_kernel<sel4> (3x3 stride-2 input gradient) M=%d N=%d K=%d" % (N * Ho * Wo, 4 * cin, 4 * cout),
+                           2.0 * N * Ho * Wo * cout * 9 * cin, lambda: _lib.check(
+                    _lib.lib().mdm_conv_s2_dgrad(_p(dy), _p(wsel), _p(dxb), N, Ho, Wo, cout, cin, BF16, _stream()), "mdm_conv_s2_dgrad"))
+                _lib.check(_lib.lib().mdm_depth_to_space2x(_p(dxb), _p(dx), N, Ho, Wo, cin, BF16, _stream()), "mdm_depth_to_space2x")
+            elif ks == 3 and stride == 2:
                 _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, 3, 1, 1, 0, kbd)
             else:
                 _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, ks, 1, 0, 0, kbd)

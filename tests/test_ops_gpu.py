@@ -61,6 +61,9 @@ def nchw(t_nhwc):
         (8, 127, 63, 128, 320, 3, 1),   # 256x256 forward (ragged M / N), 128x128 input gradient
         (8, 127, 63, 128, 264, 1, 1),   # 256x256, 1x1
         (8, 254, 126, 64, 264, 3, 2),   # 256x256, stride 2
+        # stride 2 with Cout % 64 == 0, even H / W (bf16): the pixel-unshuffled input gradient (mdm_conv_s2_dgrad)
+        (2, 32, 32, 256, 256, 3, 2),
+        (4, 64, 48, 128, 192, 3, 2),    # ragged tiles of the 4 Cin = 512 wide output
         # power-of-two images / 1x1: the buffer-addressed wgrad (conv_wgrad_bl_kernel)
         (3, 4, 8, 64, 72, 3, 1),        # 128x128 tile, ragged reduction tail (M = 96), image borders everywhere
         (5, 9, 7, 64, 136, 1, 1),       # 128x128, 1x1, M = 315
