@@ -82,15 +82,34 @@ int mdm_conv_fwd_plan(int M, int Cout, int K, int dtype, int* splits, size_t* ws
 int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float* bias, const void* res, const void* aux, void* y,
                     void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride,
                     int transposed, int act, int kblock, int dtype, float* ws, size_t ws_bytes, void* stream);
-/* mdm_conv_s2_dgrad + mdm_depth_to_space2x (ABI 3): input gradient of a STRIDE-2 3x3 convolution (pad 1, even H, W;
- *   bf16) -- replaces the backward of the downsampling conv (models/unet.py:514-522).  dx[2b + p] only draws from
- *   dy[b] and dy[b + 1], so over the 2x2-blocked dx it is a 2x2 stride-1 correlation: dxb [N, Ho, Wo, 4 Cin] (channel
- *   (ph, pw, ci)) from dy [N, Ho, Wo, Cout] and w_sel [4 Cin][Cout / 64][4][64] (tap j = 2 dh + dw; zeros where a
- *   (phase, offset) pair has no tap); mdm_depth_to_space2x then writes dx [N, 2 Ho, 2 Wo, Cin].  2.25x fewer
- *   multiply-adds than the zero-upsampled 3x3 form of mdm_conv_fwd(transposed = 1), which stays for fp32 / odd sizes. */
-int mdm_conv_s2_dgrad(const void* dy, const void* w_sel, void* dxb, int N, int Ho, int Wo, int Cout, int Cin, int dtype,
+/* Sub-pixel forms of the resampling convolutions (ABI 3; bf16).  A stride-2 3x3 convolution (models/unet.py:514-522) and
+ * a 3x3 convolution of a nearest-2x-upsampled image (unet.py:567-569) touch, per 2x2 block of the high-resolution side,
+ * 2x2 low-resolution pixels per phase: over 2x2-blocked tensors they are 2x2 correlations -- 16 weight blocks instead of
+ * 36, 2.25x fewer multiply-adds -- and the upsampled tensor never exists.
+ *   mdm_conv_s2_dgrad     dx [N, 2Ho, 2Wo, Cin] of the stride-2 conv from dy [N, Ho, Wo, Cout]; w_sel [4 Cin][Cout/64][4][64]
+ *                         (row (ph, pw, ci), tap j = 2 dh + dw reads dy[b + d]; zeros where a phase has no tap).
+ *                         Cout % 64 == 0, Cin % 128 == 0, even H / W.  mdm_conv_fwd(transposed = 1) stays for the rest.
+ *   mdm_upconv_pack       w (Cout, Cin, 3, 3) fp32 -> w_ph [4 Cout][Cin/64][4][64] (forward) and w_t [Cin][4][Cout/64][4][64]
+ *                         (input gradient): the 3x3 taps that fall on one low-resolution pixel of a phase, summed.
+ *   mdm_conv_up_fwd       y [N, 2H, 2W, Cout] = conv3x3(upsample2x(x)) + bias from x [N, H, W, Cin]; bias4 = bias x 4 phases.
+ *   mdm_space_to_depth2x  dyb [N, H, W, 4C] (channel (ph, pw, c)) from dy [N, 2H, 2W, C]: operand of the two gradients
+ *   mdm_conv_up_dgrad     dx [N, H, W, Cin] from dyb and w_t.
+ *   mdm_conv_wgrad_blocked + mdm_conv_wgrad_reduce(Cout = 4 Cout, ksize 3) + mdm_upconv_wfold
+ *                         dW (Cout, Cin, 3, 3) (+)=, dbias (+)=: the split GEMM over x and dyb computes only the 16 needed
+ *                         (phase, tap) blocks of dwb (4 Cout, Cin, 3, 3); the fold adds them into the 3x3 taps.
+ *                         ws as mdm_conv_wgrad_plan(N H W, 4 Cout, 9 Cin).  Cin % 256 == 0, Cout % 256 == 0, H / W powers of 2. */
+int mdm_conv_s2_dgrad(const void* dy, const void* w_sel, void* dx, int N, int Ho, int Wo, int Cout, int Cin, int dtype,
                       void* stream);
-int mdm_depth_to_space2x(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+int mdm_upconv_pack(const float* w_oihw, void* w_ph, void* w_t, int Cout, int Cin, void* stream);
+int mdm_conv_up_fwd(const void* x, const void* w_ph, const float* bias4, void* y, int N, int H, int W, int Cin, int Cout,
+                    int dtype, void* stream);
+int mdm_space_to_depth2x(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+int mdm_conv_up_dgrad(const void* dyb, const void* w_t, void* dx, int N, int H, int W, int Cout, int Cin, int dtype,
+                      void* stream);
+int mdm_conv_wgrad_blocked(const void* x, const void* dyb, int want_bias, float* ws, int N, int H, int W, int Cin, int Cout,
+                           int dtype, void* stream);
+int mdm_upconv_wfold(const float* dwb, float* dw, const float* dbias4, float* dbias, int Cout, int Cin, int accumulate,
+                     void* stream);
 int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* splits_out, size_t* ws_bytes);
 int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, float* ws, int N, int H, int W, int Cin, int Ho,
                    int Wo, int Cout, int ksize, int stride, int dtype, void* stream);

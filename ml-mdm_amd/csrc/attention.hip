@@ -1244,8 +1244,13 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
   a.dkc = dkc; a.dvc = dvc; a.dkc_bs = dc_bs; a.dkc_rs = dc_rs;
   if constexpr (sizeof(T) == 2) {
     // short sequences: one block per (batch, head), operands LDS-resident (attn_bwd_small_kernel)
-    static const bool split_only = getenv("MDM_HIP_ATTN_BWD_SPLIT") != nullptr;   // development A/B switch
-    if (a.L <= 256 && (!a.kc || a.S <= 64) && !split_only) {
+    // MDM_HIP_ATTN_BWD = "split" (never) / "small" (whenever the shape allows; the tests) overrides the choice below
+    const char* const mode_env = getenv("MDM_HIP_ATTN_BWD");
+    const bool split_only = mode_env && mode_env[0] == 's' && mode_env[1] == 'p';
+    const bool force_small = mode_env && mode_env[0] == 's' && mode_env[1] == 'm';
+    // (one block per head: worth it once the heads fill the chip -- at batch 16 the 128 blocks of the 64x64 U-Net's
+    // 16x16 level would leave half the CUs idle, and the streaming kernels' 4 + 5 blocks per head win)
+    if (a.L <= 256 && (!a.kc || a.S <= 64) && (a.B * a.H >= device_cus() || force_small) && !split_only) {
       constexpr int smem_small = 8 * G::NAT_BYTES + 4096;
       ensure_dynamic_lds(attn_bwd_small_kernel<D>, smem_small);
       hipLaunchKernelGGL((attn_bwd_small_kernel<D>), dim3(a.B * a.H), dim3(512), smem_small, st, a);

@@ -68,19 +68,20 @@ __global__ void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, in
     reinterpret_cast<uint4*>(y)[i] = reinterpret_cast<const uint4*>(x)[s];
   }
 }
-// pixel shuffle of a 2x2-blocked tensor: y[n, 2h + a, 2w + b, c] = x[n, h, w, (2a + b) * C + c]
+// 2x2 pixel blocks -> channels: y[n, h, w, (2a + b) * C + c] = x[n, 2h + a, 2w + b, c]
 template <typename T>
-__global__ void depth_to_space2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
+__global__ void space_to_depth2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
   constexpr int EPV = Tr<T>::EPV;
   const int k = C / EPV;
   const size_t total = (size_t)N * 4 * H * W * k;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int cc = (int)(i % k);
     size_t p = i / k;
-    const int ow = (int)(p % (2 * W)); p /= (2 * W);
-    const int oh = (int)(p % (2 * H));
-    const int n = (int)(p / (2 * H));
-    const size_t s = ((((size_t)n * H + (oh >> 1)) * W + (ow >> 1)) * 4 + ((oh & 1) * 2 + (ow & 1))) * k + cc;
+    const int ph = (int)(p % 4); p /= 4;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    const size_t s = ((((size_t)n * 2 * H + 2 * h + (ph >> 1)) * 2 * W) + 2 * w + (ph & 1)) * k + cc;
     reinterpret_cast<uint4*>(y)[i] = reinterpret_cast<const uint4*>(x)[s];
   }
 }
@@ -230,14 +231,14 @@ extern "C" int mdm_upsample2x(const void* x, void* y, int N, int H, int W, int C
   MDM_LAUNCH_STATUS();
 }
 
-// y [N, 2H, 2W, C] from the 2x2-blocked x [N, H, W, 4C] (mdm_conv_s2_dgrad's output -> the input gradient proper)
-extern "C" int mdm_depth_to_space2x(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+// y [N, H, W, 4C] (2x2 blocks, channel (2a + b, c)) from x [N, 2H, 2W, C]
+extern "C" int mdm_space_to_depth2x(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
   MDM_CHECK_ARG(x && y);
   const int epv = dtype == DT_F32 ? 4 : 8;
   MDM_CHECK_ARG(C % epv == 0);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t total = (size_t)N * 4 * H * W * (C / epv);
-  MDM_DISPATCH_T(dtype, hipLaunchKernelGGL(depth_to_space2x_kernel<TT>, dim3(ew_blocks(total)), dim3(256), 0, st, (const TT*)x, (TT*)y, N, H, W, C));
+  MDM_DISPATCH_T(dtype, hipLaunchKernelGGL(space_to_depth2x_kernel<TT>, dim3(ew_blocks(total)), dim3(256), 0, st, (const TT*)x, (TT*)y, N, H, W, C));
   MDM_LAUNCH_STATUS();
 }
 

@@ -48,6 +48,16 @@ struct ConvArgs {
   // range s writes its raw fp32 tile to part[s][M][Cout]; splitk_epilogue_kernel adds them up and applies the epilogue
   float* part;
   int ksplit, kt_per;
+  // tap selection (conv_gemm_bl_kernel<..., SEL4>): 4 of the 9 taps per channel block, tap = base + (j & 1) + 3 * (j >> 1)
+  //   sel_mode 0: one base for the whole launch (sel_base; 4 = the stride-2 input gradient)
+  //   sel_mode 1: base by OUTPUT phase, phase = column tile's n0 / sel_cout (sub-pixel form of upsample2x -> conv3x3:
+  //               output columns are (phase, co), phase (ph, pw) reads the low-res taps {ph, ph+1} x {pw, pw+1})
+  //   sel_mode 2: base by INPUT phase: the reduction runs over (phase, channel block, tap) of a 2x2-blocked input with
+  //               sel_cout channels per phase (input gradient of the same op); base = (1 - ph) * 3 + (1 - pw)
+  int sel_mode, sel_base, sel_cout;
+  // pixel-shuffled store (ps_cout > 0): output column (phase, co), row (n, bh, bw) of a ps_H x ps_W grid goes to
+  // y[n, 2 bh + ph, 2 bw + pw, co] of a [N, 2 ps_H, 2 ps_W, ps_cout] tensor (a column tile lies inside one phase)
+  int ps_cout, ps_H, ps_W;
 };
 
 enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };
@@ -168,7 +178,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
       const int m = m0 + row, n = n0 + ch * EPV;
       if (m >= p.M || n >= p.Cout) continue;
       if (g_knobs[1]) continue;
-      const size_t o = (size_t)m * p.Cout + n;
+      size_t o = (size_t)m * p.Cout + n;
+      if (p.ps_cout > 0) {   // (phase, co) column of low-res pixel (n, bh, bw) -> its place in the 2x larger image
+        const int ph = n / p.ps_cout, co = n - ph * p.ps_cout;
+        const int bw = m % p.ps_W, t_ = m / p.ps_W;
+        const int bh = t_ % p.ps_H, img = t_ / p.ps_H;
+        o = (((size_t)img * (2 * p.ps_H) + 2 * bh + (ph >> 1)) * (2 * p.ps_W) + 2 * bw + (ph & 1)) * p.ps_cout + co;
+      }
       if (act == 0 && !R) {
         *reinterpret_cast<uint4*>(Y + o) = raw[i];
         continue;
@@ -439,6 +455,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   const unsigned bias = MODE == MODE_3x3 ? (unsigned)(p.W + 1) * p.Cin * 2u : 0u;   // base shift that keeps the per-tap scalar offset non-negative
   unsigned a_voff[AJ], a_mask[AJ], b_voff[BJ];
   int m0 = 0, n0 = 0, grp = 0;
+  int sel_base_tile = p.sel_base;                     // SEL4: tap base of the current output tile
+  const int kpp_ = (p.sel_cout >> 6) * 4;             // SEL4, sel_mode 2: k-tiles per input phase
   int split = 0, kt0 = 0, nloc = p.K / 64;   // SPLITK: this tile's reduction range = k-tiles [kt0, kt0 + nloc)
   char* a_base = const_cast<char*>(reinterpret_cast<const char*>(p.x)) - bias;
   char* b_base = const_cast<char*>(reinterpret_cast<const char*>(p.w));
@@ -455,6 +473,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
       kt0 = split * p.kt_per; nloc = min(p.kt_per, p.K / 64 - kt0);                                         \
     }                                                                                                       \
     m0 = (tl_ / tiles_n) * BM; n0 = (tl_ % tiles_n) * BN;                                                   \
+    if constexpr (SEL4) {                                                                                   \
+      if (p.sel_mode == 1) { const int ph_ = n0 / p.sel_cout; sel_base_tile = (ph_ >> 1) * 3 + (ph_ & 1); } \
+    }                                                                                                       \
     _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                        \
       const int m = m0 + lrow + RPP * j;                                                                    \
       a_voff[j] = INVALID; a_mask[j] = 0u;                                                                  \
@@ -499,8 +520,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   const int b_soff = kta_ * 128;                                                                            \
   int a_soff = b_soff, tapbit = 1;                                                                          \
   if (MODE == MODE_3x3) {                                                                                   \
-    const int cb = SEL4 ? kta_ >> 2 : kta_ / 9;                                                             \
-    const int tap = SEL4 ? 4 + (kta_ & 1) + 3 * ((kta_ >> 1) & 1) : kta_ - 9 * cb;                          \
+    int cb, tap;                                                                                            \
+    if constexpr (SEL4) {                                                                                   \
+      int r_ = kta_, base_ = sel_base_tile, coff_ = 0;                                                      \
+      if (p.sel_mode == 2) {   /* phase of this k-tile: kpp_ k-tiles per phase */                           \
+        const int ph_ = (kta_ >= kpp_) + (kta_ >= 2 * kpp_) + (kta_ >= 3 * kpp_);                           \
+        r_ = kta_ - ph_ * kpp_;                                                                             \
+        base_ = (1 - (ph_ >> 1)) * 3 + (1 - (ph_ & 1));                                                     \
+        coff_ = ph_ * (p.sel_cout >> 6);                                                                    \
+      }                                                                                                     \
+      cb = coff_ + (r_ >> 2);                                                                               \
+      tap = base_ + (r_ & 1) + 3 * ((r_ >> 1) & 1);                                                         \
+    } else {                                                                                                \
+      cb = kta_ / 9; tap = kta_ - 9 * cb;                                                                   \
+    }                                                                                                       \
     const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;                                                      \
     a_soff = (kh * p.W + kw) * p.Cin * 2 + cb * 128;                                                        \
     tapbit = 1 << tap;                                                                                      \
@@ -648,6 +681,9 @@ struct WgradArgs {
   int M, K;
   int splits, mtiles_per_split;
   int groups;       // conv_wgrad_bl_kernel only: > 0 = grouped launch over `groups` same-shape problems (WgradGroup)
+  int skip_cout;    // conv_wgrad_bl_kernel, 3x3 only: > 0 = dY is a 2x2-blocked gradient with skip_cout channels per phase
+                    // (sub-pixel form of upsample2x -> conv3x3): output tile (phase, tap) is computed only for the four
+                    // taps {ph, ph+1} x {pw, pw+1} its phase reads; the other tiles of the slab stay unwritten
 };
 
 // Grouped weight gradient (1x1, bf16): G same-shape layers in ONE launch.  The 26 attention layers of the 16x16 level
@@ -1240,6 +1276,11 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
   const int split = lid / tiles;
   const int t = lid - split * tiles;
   const int n0 = (t / tiles_k) * BM, k0 = (t % tiles_k) * BN;
+  if (MODE == MODE_3x3 && p.skip_cout > 0) {
+    const int ph = n0 / p.skip_cout, tp = k0 / p.Cin;   // tiles never straddle a phase / a tap (host-checked)
+    const int dj = tp / 3 - (ph >> 1), dk = tp % 3 - (ph & 1);
+    if ((unsigned)dj > 1u || (unsigned)dk > 1u) return;   // block-uniform, before any barrier
+  }
   const void* const x_ptr = p.groups > 0 ? gr.x[grp] : p.x;
   const void* const dy_ptr = p.groups > 0 ? gr.dy[grp] : p.dy;
 
@@ -1303,7 +1344,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = (p.groups > 0 ? gr.bout[grp] != nullptr : p.bslab != nullptr) && k0 == 0 && wn == 0;
+  // (with tile skipping the first tile a phase computes is its first tap's, not tap 0's)
+  const int bias_k0 = (MODE == MODE_3x3 && p.skip_cout > 0) ? (((n0 / p.skip_cout) >> 1) * 3 + ((n0 / p.skip_cout) & 1)) * p.Cin : 0;
+  const bool do_bias = (p.groups > 0 ? gr.bout[grp] != nullptr : p.bslab != nullptr) && k0 == bias_k0 && wn == 0;
   // bias gradient = column sums of dY: the waves that own k-tile 0 add up the dY^T fragments they already hold
   // (8 pixels of one channel per lane) with v_dot2c_f32_bf16 against (1, 1) -- one fp32 register per fragment row
   float bsum[MT];
@@ -1754,6 +1797,84 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   for (int e = 0; e < 4; ++e) y[idx + e] = from_f32<T>(v[e]);
 }
 
+// ---- sub-pixel form of upsample2x -> conv3x3: weight packs and the weight-gradient fold ----------------------------
+// Row taps of the 3x3 kernel that land on low-resolution offset index a (0, 1) of output phase ph (0, 1):
+//   ph = 0: a = 0 (row b - 1) <- {kh 0},  a = 1 (row b) <- {kh 1, 2};   ph = 1: a = 0 (row b) <- {kh 0, 1},  a = 1 (row b + 1) <- {kh 2}
+__device__ __forceinline__ bool up_tap_in(int ph, int a, int kh) {
+  return ph == 0 ? (a == 0 ? kh == 0 : kh >= 1) : (a == 0 ? kh <= 1 : kh == 2);
+}
+// one thread per (co, ci): w (Cout, Cin, 3, 3) fp32 -> w_ph [4 Cout][Cin / 64][4][64] and w_t [Cin][4][Cout / 64][4][64] (bf16)
+__global__ __launch_bounds__(256) void upconv_pack_kernel(const float* __restrict__ w, bf16* __restrict__ w_ph,
+                                                          bf16* __restrict__ w_t, int Cout, int Cin) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Cout * Cin) return;
+  const int co = idx / Cin, ci = idx - co * Cin;
+  float t[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) t[k] = w[(size_t)idx * 9 + k];
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float v = 0.f;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+              if (up_tap_in(ph, a, kh) && up_tap_in(pw, b, kw)) v += t[kh * 3 + kw];
+          const int phase = ph * 2 + pw;
+          // forward: row (phase, co), k = (ci / 64, tap j = 2a + b, ci % 64)
+          w_ph[((size_t)(phase * Cout + co) * (Cin >> 6) + (ci >> 6)) * 256 + (a * 2 + b) * 64 + (ci & 63)] = (bf16)v;
+          // input gradient: row ci, k = (phase, co / 64, tap j = 2 dj + dk with dj = 1 - a, dk = 1 - b, co % 64)
+          w_t[(((size_t)ci * 4 + phase) * (Cout >> 6) + (co >> 6)) * 256 + ((1 - a) * 2 + (1 - b)) * 64 + (co & 63)] = (bf16)v;
+        }
+}
+
+// dW (Cout, Cin, 3, 3) (+)= the fold of dwb (4 Cout, Cin, 3, 3): the gradient of phase weight (ph, a) x (pw, b) -- stored at
+// low-resolution tap (ph + a, pw + b) of row (phase, co) -- flows to every 3x3 tap summed into it.  Only the 16 computed
+// (phase, tap) blocks are read.  One thread per (co, ci).
+__global__ __launch_bounds__(256) void upconv_wfold_kernel(const float* __restrict__ dwb, float* __restrict__ dw, int Cout,
+                                                           int Cin, int accumulate) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Cout * Cin) return;
+  const int co = idx / Cin, ci = idx - co * Cin;
+  float o[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) o[k] = 0.f;
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float g = dwb[((size_t)((ph * 2 + pw) * Cout + co) * Cin + ci) * 9 + (ph + a) * 3 + (pw + b)];
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+              if (up_tap_in(ph, a, kh) && up_tap_in(pw, b, kw)) o[kh * 3 + kw] += g;
+        }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    float* d = dw + (size_t)idx * 9 + k;
+    *d = accumulate ? *d + o[k] : o[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void upconv_bfold_kernel(const float* __restrict__ db4, float* __restrict__ db, int Cout,
+                                                           int accumulate) {
+  const int co = blockIdx.x * 256 + threadIdx.x;
+  if (co >= Cout) return;
+  const float v = (db4[co] + db4[Cout + co]) + (db4[2 * Cout + co] + db4[3 * Cout + co]);
+  db[co] = accumulate ? db[co] + v : v;
+}
+
 static thread_local char g_last_gemm[96] = "";
 extern "C" const char* mdm_last_gemm_kernel(void) { return g_last_gemm; }
 #define MDM_NOTE_KERNEL(...) snprintf(g_last_gemm, sizeof(g_last_gemm), __VA_ARGS__)
@@ -1923,7 +2044,7 @@ extern "C" int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float*
   if (ksize == 1) { MDM_CHECK_ARG(Ho == H && Wo == W && stride == 1 && !transposed); }
   else if (transposed) { MDM_CHECK_ARG(Ho == 2 * H && Wo == 2 * W); }
   else { MDM_CHECK_ARG(stride == 1 || stride == 2); MDM_CHECK_ARG(Ho == (H - 1) / stride + 1 && Wo == (W - 1) / stride + 1); }
-  ConvArgs a;
+  ConvArgs a = {};
   a.x = x; a.w = w_packed; a.bias = bias; a.res = res; a.aux = aux; a.y = y; a.ypre = y_pre;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.stride = stride;
   a.M = N * Ho * Wo; a.K = ksize * ksize * Cin; a.act = act; a.groups = 0;
@@ -1951,26 +2072,96 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
 }
 
 
-// Input gradient of a stride-2 3x3 convolution (pad 1, even H and W) in pixel-unshuffled form, bf16:
-//   dxb [N, Ho, Wo, 4 Cin] with channel (ph, pw, ci) = dx[n, 2 bh + ph, 2 bw + pw, ci]
-//       = sum over (dh, dw) in {0, 1}^2, co of dy[n, bh + dh, bw + dw, co] * w_sel[(ph, pw, ci)][(dh, dw)][co]
-// w_sel: [4 Cin][Cout / 64][4 taps][64] (channel-block-major, tap j = 2 dh + dw), zero where the (phase, offset) pair has
-// no tap of the 3x3 kernel (7 of 16).  2.25x fewer multiply-adds than the zero-upsampled 3x3 formulation and the
-// buffer-addressed k-loop; mdm_depth_to_space2x turns dxb into dx.  Cout % 64 == 0, Cin % 2 == 0.
-extern "C" int mdm_conv_s2_dgrad(const void* dy, const void* w_sel, void* dxb, int N, int Ho, int Wo, int Cout, int Cin,
-                                 int dtype, void* stream) {
-  MDM_CHECK_ARG(dy && w_sel && dxb && dtype == DT_BF16);
-  MDM_CHECK_ARG(N > 0 && Ho > 0 && Wo > 0 && Cout % 64 == 0 && Cin > 0 && (4 * Cin) % 8 == 0);
-  ConvArgs a = {};
-  a.x = dy; a.w = w_sel; a.y = dxb;
-  a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Ho = Ho; a.Wo = Wo; a.Cout = 4 * Cin; a.stride = 1;
-  a.M = N * Ho * Wo; a.K = 4 * Cout; a.act = 0; a.groups = 0; a.kblk = 64; a.ksplit = 1;
-  MDM_CHECK_ARG((conv_bl_ok<bf16, MODE_3x3>(a)));
+// w (Cout, Cin, 3, 3) fp32 -> the two bf16 packs of the sub-pixel upsample convolution (mdm_conv_up_fwd / _dgrad)
+extern "C" int mdm_upconv_pack(const float* w_oihw, void* w_ph, void* w_t, int Cout, int Cin, void* stream) {
+  MDM_CHECK_ARG(w_oihw && w_ph && w_t && Cout % 64 == 0 && Cin % 64 == 0);
+  hipLaunchKernelGGL(upconv_pack_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     w_oihw, (bf16*)w_ph, (bf16*)w_t, Cout, Cin);
+  MDM_LAUNCH_STATUS();
+}
+// dW (Cout, Cin, 3, 3) (+)= fold of dwb (4 Cout, Cin, 3, 3) (see mdm_conv_wgrad_blocked); dbias (Cout) (+)= the four
+// phase sums of dbias4 (4 Cout) when both are given
+extern "C" int mdm_upconv_wfold(const float* dwb, float* dw, const float* dbias4, float* dbias, int Cout, int Cin,
+                                int accumulate, void* stream) {
+  MDM_CHECK_ARG(dwb && dw && Cout > 0 && Cin > 0 && ((dbias4 == nullptr) == (dbias == nullptr)));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int code = conv_tile_code(a.M, a.Cout, DT_BF16);
-  if (code == 256256) return launch_conv_bl_sel4<256, 256, 2, 4>(a, st);
-  if (code == 256192) return launch_conv_bl_sel4<256, 192, 2, 4>(a, st);
+  hipLaunchKernelGGL(upconv_wfold_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, st, dwb, dw, Cout, Cin, accumulate);
+  if (dbias) hipLaunchKernelGGL(upconv_bfold_kernel, dim3((Cout + 255) / 256), dim3(256), 0, st, dbias4, dbias, Cout, accumulate);
+  MDM_LAUNCH_STATUS();
+}
+
+// ---- sub-pixel forms of the resampling convolutions (bf16) -------------------------------------------------------
+// A stride-2 3x3 convolution and a 3x3 convolution of a nearest-2x-upsampled image both touch, per 2x2 block of the
+// high-resolution side, only 2x2 pixels of the low-resolution side per output phase: written over 2x2-blocked tensors
+// they are 2x2 correlations, 16 (phase, offset) weight blocks instead of 36 (phase, tap) -- 2.25x fewer multiply-adds
+// than the dense 3x3 over the high-resolution grid -- and the 4x larger upsampled tensor never exists.
+// The launches below are conv_gemm_bl_kernel<.., SEL4> (4 taps per channel block); a column tile must lie inside one
+// phase, so the per-phase width picks the tile.
+static int sel4_tile(int cols_per_phase) {
+  return cols_per_phase % 256 == 0 ? 256 : (cols_per_phase % 192 == 0 ? 192 : (cols_per_phase % 128 == 0 ? 128 : 0));
+}
+static int launch_sel4(const ConvArgs& a, int tile, hipStream_t st) {
+  if (tile == 256) return launch_conv_bl_sel4<256, 256, 2, 4>(a, st);
+  if (tile == 192) return launch_conv_bl_sel4<256, 192, 2, 4>(a, st);
   return launch_conv_bl_sel4<128, 128, 2, 2>(a, st);
+}
+
+// Input gradient of a stride-2 3x3 convolution (pad 1, even H and W): dx [N, 2 Ho, 2 Wo, Cin] from dy [N, Ho, Wo, Cout]:
+//   dx[n, 2 bh + ph, 2 bw + pw, ci] = sum over (dh, dw) in {0, 1}^2, co of dy[n, bh + dh, bw + dw, co] * w_sel[(ph, pw, ci)][(dh, dw)][co]
+// w_sel: [4 Cin][Cout / 64][4 taps][64] (channel-block-major, tap j = 2 dh + dw), zero where the (phase, offset) pair has
+// no tap of the 3x3 kernel (7 of 16).  Cout % 64 == 0, Cin % 128 == 0.
+extern "C" int mdm_conv_s2_dgrad(const void* dy, const void* w_sel, void* dx, int N, int Ho, int Wo, int Cout, int Cin,
+                                 int dtype, void* stream) {
+  MDM_CHECK_ARG(dy && w_sel && dx && dtype == DT_BF16);
+  MDM_CHECK_ARG(N > 0 && Ho > 0 && Wo > 0 && Cout % 64 == 0 && Cin > 0);
+  const int tile = sel4_tile(Cin);
+  MDM_CHECK_ARG(tile != 0);
+  ConvArgs a = {};
+  a.x = dy; a.w = w_sel; a.y = dx;
+  a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Ho = Ho; a.Wo = Wo; a.Cout = 4 * Cin; a.stride = 1;
+  a.M = N * Ho * Wo; a.K = 4 * Cout; a.kblk = 64; a.ksplit = 1;
+  a.sel_mode = 0; a.sel_base = 4;
+  a.ps_cout = Cin; a.ps_H = Ho; a.ps_W = Wo;
+  MDM_CHECK_ARG((conv_bl_ok<bf16, MODE_3x3>(a)));
+  return launch_sel4(a, tile, reinterpret_cast<hipStream_t>(stream));
+}
+
+// y [N, 2H, 2W, Cout] = conv3x3(upsample2x_nearest(x), w) + bias from the LOW-resolution x [N, H, W, Cin]:
+//   y[n, 2 bh + ph, 2 bw + pw, co] = bias[co] + sum over (dj, dk) in {0, 1}^2, ci of x[n, bh + ph - 1 + dj, bw + pw - 1 + dk, ci] * w_ph[(ph, pw, co)][(dj, dk)][ci]
+// w_ph: [4 Cout][Cin / 64][4][64]: the 3x3 taps that fall on the same low-resolution pixel for this phase, summed.
+// bias4: [4 Cout] (the bias repeated per phase) or NULL.  Cin % 64 == 0, Cout % 128 == 0.
+extern "C" int mdm_conv_up_fwd(const void* x, const void* w_ph, const float* bias4, void* y, int N, int H, int W, int Cin,
+                               int Cout, int dtype, void* stream) {
+  MDM_CHECK_ARG(x && w_ph && y && dtype == DT_BF16);
+  MDM_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cout > 0);
+  const int tile = sel4_tile(Cout);
+  MDM_CHECK_ARG(tile != 0);
+  ConvArgs a = {};
+  a.x = x; a.w = w_ph; a.bias = bias4; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = H; a.Wo = W; a.Cout = 4 * Cout; a.stride = 1;
+  a.M = N * H * W; a.K = 4 * Cin; a.kblk = 64; a.ksplit = 1;
+  a.sel_mode = 1; a.sel_cout = Cout;
+  a.ps_cout = Cout; a.ps_H = H; a.ps_W = W;
+  MDM_CHECK_ARG((conv_bl_ok<bf16, MODE_3x3>(a)));
+  return launch_sel4(a, tile, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Input gradient of the same operation: dx [N, H, W, Cin] from the 2x2-BLOCKED output gradient dyb [N, H, W, 4 Cout]
+// (channel (ph, pw, co) = dy[n, 2 bh + ph, 2 bw + pw, co]; mdm_space_to_depth2x makes it):
+//   dx[n, bh, bw, ci] = sum over phases, (dj, dk), co of dyb[n, bh + dj - ph, bw + dk - pw, (ph, pw, co)] * w_t[ci][(ph, pw)][(dj, dk)][co]
+// w_t: [Cin][4 phases][Cout / 64][4][64].  Cout % 64 == 0, Cin % 8 == 0.
+extern "C" int mdm_conv_up_dgrad(const void* dyb, const void* w_t, void* dx, int N, int H, int W, int Cout, int Cin,
+                                 int dtype, void* stream) {
+  MDM_CHECK_ARG(dyb && w_t && dx && dtype == DT_BF16);
+  MDM_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout % 64 == 0 && Cin % 8 == 0);
+  ConvArgs a = {};
+  a.x = dyb; a.w = w_t; a.y = dx;
+  a.N = N; a.H = H; a.W = W; a.Cin = 4 * Cout; a.Ho = H; a.Wo = W; a.Cout = Cin; a.stride = 1;
+  a.M = N * H * W; a.K = 16 * Cout; a.kblk = 64; a.ksplit = 1;
+  a.sel_mode = 2; a.sel_cout = Cout;
+  MDM_CHECK_ARG((conv_bl_ok<bf16, MODE_3x3>(a)));
+  const int code = conv_tile_code(a.M, a.Cout, DT_BF16);
+  return launch_sel4(a, code == 256256 ? 256 : (code == 256192 ? 192 : 128), reinterpret_cast<hipStream_t>(stream));
 }
 
 // y[g] [M, Cout] = x[g] [M, Cin] * w_packed[g]^T + bias[g] for `groups` (<= 32) linear layers of one shape, bf16, in ONE
@@ -2064,15 +2255,15 @@ static bool wgrad_bl_ok(const WgradArgs& a, int ksize) {
   return (size_t)a.M * a.Cout * 2 <= lim && (size_t)a.N * a.H * a.W * a.Cin * 2 + bias <= lim;
 }
 
-extern "C" int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, float* ws, int N, int H, int W, int Cin,
-                              int Ho, int Wo, int Cout, int ksize, int stride, int dtype, void* stream) {
+static int conv_wgrad_impl(const void* x, const void* dy, int want_bias, float* ws, int N, int H, int W, int Cin,
+                           int Ho, int Wo, int Cout, int ksize, int stride, int dtype, int skip_cout, void* stream) {
   MDM_CHECK_ARG(x && dy && ws);
   MDM_CHECK_ARG(ksize == 1 || ksize == 3);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
   const int epv = dtype == DT_F32 ? 4 : 8;
   MDM_CHECK_ARG(Cin % epv == 0 && Cout % epv == 0);
-  WgradArgs a;
-  a.x = x; a.dy = dy; a.slab = ws;
+  WgradArgs a = {};
+  a.x = x; a.dy = dy; a.slab = ws; a.skip_cout = skip_cout;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.stride = stride;
   a.M = N * Ho * Wo; a.K = ksize * ksize * Cin; a.groups = 0;
   size_t wsb;
@@ -2121,6 +2312,24 @@ extern "C" int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, floa
     else hipLaunchKernelGGL((conv_wgrad_tr_kernel<MODE_3x3, 0>), grid, dim3(256), smem, st, a);
   }
   MDM_LAUNCH_STATUS();
+}
+
+extern "C" int mdm_conv_wgrad(const void* x, const void* dy, int want_bias, float* ws, int N, int H, int W, int Cin,
+                              int Ho, int Wo, int Cout, int ksize, int stride, int dtype, void* stream) {
+  return conv_wgrad_impl(x, dy, want_bias, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, dtype, 0, stream);
+}
+
+// Weight gradient of upsample2x -> conv3x3 in its sub-pixel form: the split GEMM of mdm_conv_wgrad over the LOW-resolution
+// x [N, H, W, Cin] and the 2x2-blocked gradient dyb [N, H, W, 4 Cout] (channel (ph, pw, co)), computing for every phase
+// only the four low-resolution taps it reads (16 of the 36 (phase, tap) blocks).  ws / splits as for
+// mdm_conv_wgrad_plan(M = N H W, 4 Cout, 9 Cin); mdm_conv_wgrad_reduce(.., Cout = 4 Cout, ksize 3, ..) then gives
+// dwb (4 Cout, Cin, 3, 3) whose computed blocks mdm_upconv_wfold adds up into dW (Cout, Cin, 3, 3).
+// bf16, H and W powers of two, Cin % 256 == 0, Cout % 256 == 0.
+extern "C" int mdm_conv_wgrad_blocked(const void* x, const void* dyb, int want_bias, float* ws, int N, int H, int W, int Cin,
+                                      int Cout, int dtype, void* stream) {
+  MDM_CHECK_ARG(dtype == DT_BF16 && Cin % 256 == 0 && Cout % 256 == 0);
+  MDM_CHECK_ARG((H & (H - 1)) == 0 && (W & (W - 1)) == 0);
+  return conv_wgrad_impl(x, dyb, want_bias, ws, N, H, W, Cin, H, W, 4 * Cout, 3, 1, dtype, Cout, stream);
 }
 
 // Tile edge of a grouped 1x1 weight gradient, or 0 when grouping `groups` problems of this shape would not fill the

@@ -643,15 +643,13 @@ class ConvFn(torch.autograd.Function):
             if wd is None:
                 raise _lib.MdmHipError("input gradient requested for a channel-padded convolution")
             dx = torch.empty_like(x)
-            if ks == 3 and stride == 2 and x.dtype == torch.bfloat16 and cout_pad == cout and cout % 64 == 0 and cin % 2 == 0 \
+            if ks == 3 and stride == 2 and x.dtype == torch.bfloat16 and cout_pad == cout and cout % 64 == 0 and cin % 128 == 0 \
                     and H % 2 == 0 and W % 2 == 0:
-                # the pixel-unshuffled form: a 2x2 correlation over dy producing 4 Cin channels per 2x2 block of dx
+                # sub-pixel form: a 2x2 correlation over dy per phase of dx, stored pixel-shuffled (mdm_conv_s2_dgrad)
                 wsel = packed_s2_dgrad_weight(weight)
-                dxb = torch.empty((N, Ho, Wo, 4 * cin), dtype=x.dtype, device=x.device)
                 _prof_wrap("conv_gemm_bl_kernel<sel4> (3x3 stride-2 input gradient) M=%d N=%d K=%d" % (N * Ho * Wo, 4 * cin, 4 * cout),
                            2.0 * N * Ho * Wo * cout * 9 * cin, lambda: _lib.check(
-                    _lib.lib().mdm_conv_s2_dgrad(_p(dy), _p(wsel), _p(dxb), N, Ho, Wo, cout, cin, BF16, _stream()), "mdm_conv_s2_dgrad"))
-                _lib.check(_lib.lib().mdm_depth_to_space2x(_p(dxb), _p(dx), N, Ho, Wo, cin, BF16, _stream()), "mdm_depth_to_space2x")
+                    _lib.lib().mdm_conv_s2_dgrad(_p(dy), _p(wsel), _p(dx), N, Ho, Wo, cout, cin, BF16, _stream()), "mdm_conv_s2_dgrad"))
             elif ks == 3 and stride == 2:
                 _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, 3, 1, 1, 0, kbd)
             else:
@@ -688,6 +686,116 @@ class ConvFn(torch.autograd.Function):
 
 def conv(x, weight, bias=None, residual=None, stride=1):
     return ConvFn.apply(x, weight, bias, residual, stride)
+
+
+# --------------------------------------------------------------------------------------
+# upsample2x (nearest) -> conv3x3 in its sub-pixel form
+# --------------------------------------------------------------------------------------
+def packed_upconv_weights(weight: torch.Tensor, bias):
+    """(w_ph, w_t, bias4) of mdm_conv_up_fwd / mdm_conv_up_dgrad for a (Cout, Cin, 3, 3) weight; cached per version."""
+    ent = _cache_slot(weight)
+    ver = (weight._version, None if bias is None else bias._version, weight.data_ptr(), _pack_epoch)
+    if "upconv" in ent and ent["upconv"][0] == ver:
+        return ent["upconv"][1]
+    cout, cin = weight.shape[0], weight.shape[1]
+    prev = ent["upconv"][1] if "upconv" in ent else None
+    if prev is not None and prev[0].device == weight.device:
+        w_ph, w_t = prev[0], prev[1]
+    else:
+        w_ph = torch.empty(4 * cout * 4 * cin, dtype=torch.bfloat16, device=weight.device)
+        w_t = torch.empty(cin * 16 * cout, dtype=torch.bfloat16, device=weight.device)
+    _lib.check(_lib.lib().mdm_upconv_pack(_p(_c(weight.detach().float())), _p(w_ph), _p(w_t), cout, cin, _stream()), "mdm_upconv_pack")
+    bias4 = _c(bias.detach().float().repeat(4)) if bias is not None else None
+    val = (w_ph, w_t, bias4)
+    ent["upconv"] = (ver, val)
+    return val
+
+
+def upsample_conv_supported(x, weight):
+    """bf16, channel counts the 256-square weight-gradient tiles divide, power-of-two images (the sampling / fp32 /
+    odd-size cases take upsample2x + conv)"""
+    if os.environ.get("MDM_HIP_UPCONV", "1") == "0":   # development A/B switch
+        return False
+    return x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and weight.dim() == 4 and weight.shape[2] == 3 and \
+        weight.shape[0] % 256 == 0 and weight.shape[1] % 256 == 0 and x.shape[-1] == weight.shape[1] and \
+        (x.shape[1] & (x.shape[1] - 1)) == 0 and (x.shape[2] & (x.shape[2] - 1)) == 0
+
+
+class UpsampleConvFn(torch.autograd.Function):
+    """y = conv3x3(upsample2x_nearest(x), weight) + bias (reference unet.py:567-569) without the upsampled tensor: per
+    output phase a 2x2 correlation over the low-resolution x with the 3x3 taps that coincide summed -- 16 weight blocks
+    instead of 36 in all three directions (C ABI mdm_conv_up_fwd / _dgrad / mdm_conv_wgrad_blocked + mdm_upconv_wfold)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x)
+        x = _c(x)
+        N, H, W, cin = x.shape
+        cout = weight.shape[0]
+        w_ph, _, bias4 = packed_upconv_weights(weight, bias)
+        y = torch.empty((N, 2 * H, 2 * W, cout), dtype=x.dtype, device=x.device)
+        _prof_wrap("conv_gemm_bl_kernel<sel4> (upsample2x + 3x3) M=%d N=%d K=%d" % (N * H * W, 4 * cout, 4 * cin),
+                   2.0 * N * 4 * H * W * cout * 9 * cin, lambda: _lib.check(
+            _lib.lib().mdm_conv_up_fwd(_p(x), _p(w_ph), _p(bias4), _p(y), N, H, W, cin, cout, BF16, _stream()), "mdm_conv_up_fwd"))
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        dy = _c(dy)
+        N, H, W, cin = x.shape
+        cout = weight.shape[0]
+        L = _lib.lib()
+        _, w_t, _ = packed_upconv_weights(weight, bias)
+        dyb = torch.empty((N, H, W, 4 * cout), dtype=dy.dtype, device=dy.device)
+        _lib.check(L.mdm_space_to_depth2x(_p(dy), _p(dyb), N, H, W, cout, BF16, _stream()), "mdm_space_to_depth2x")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _prof_wrap("conv_gemm_bl_kernel<sel4> (upsample2x + 3x3 input gradient) M=%d N=%d K=%d" % (N * H * W, cin, 16 * cout),
+                       2.0 * N * 4 * H * W * cout * 9 * cin, lambda: _lib.check(
+                L.mdm_conv_up_dgrad(_p(dyb), _p(w_t), _p(dx), N, H, W, cout, cin, BF16, _stream()), "mdm_conv_up_dgrad"))
+        if ctx.needs_input_grad[1]:
+            want_b = bias is not None and ctx.needs_input_grad[2]
+            slot = _slot(weight)
+            bslot = _slot(bias) if (slot is not None and want_b) else None
+            sunk = slot is not None and (bslot is not None or not want_b)
+            M, K = N * H * W, 9 * cin
+            splits, wsb = ctypes.c_int(0), ctypes.c_size_t(0)
+            _lib.check(L.mdm_conv_wgrad_plan(M, 4 * cout, K, BF16, ctypes.byref(splits), ctypes.byref(wsb)), "mdm_conv_wgrad_plan")
+
+            def go():
+                ws = _f32_ws(wsb.value, x.device)
+                dwb = torch.empty((4 * cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+                db4 = torch.empty(4 * cout, dtype=torch.float32, device=x.device) if want_b else None
+                _prof_wrap("conv_wgrad_bl_kernel<1, 1> (upsample2x + 3x3, 16 of 36 blocks) M=%d N=%d K=%d" % (M, 4 * cout, K),
+                           2.0 * 4 * M * cout * K, lambda: _lib.check(
+                    L.mdm_conv_wgrad_blocked(_p(x), _p(dyb), 1 if want_b else 0, _p(ws), N, H, W, cin, cout, BF16, _stream()),
+                    "mdm_conv_wgrad_blocked"))
+                _lib.check(L.mdm_conv_wgrad_reduce(_p(ws), _p(dwb), _p(db4), _p(dyb), M, cin, 4 * cout, 3, 0, BF16, _stream()),
+                           "mdm_conv_wgrad_reduce")
+                dwo = slot if sunk else torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                dbo = (bslot if sunk else torch.empty(cout, dtype=torch.float32, device=x.device)) if want_b else None
+                _lib.check(L.mdm_upconv_wfold(_p(dwb), _p(dwo), _p(db4), _p(dbo), cout, cin, 1 if sunk else 0, _stream()), "mdm_upconv_wfold")
+                if sunk:
+                    _grad_sink.ready(weight)
+                    if want_b:
+                        _grad_sink.ready(bias)
+                return dwo, dbo
+
+            if sunk:
+                _off_critical_path((x, dyb), go)
+            else:
+                dw, db = go()
+        return dx, dw, db
+
+
+def upsample_conv(x, weight, bias=None):
+    """conv3x3(upsample2x(x)): the sub-pixel form where it applies, else the two separate ops"""
+    if upsample_conv_supported(x, weight):
+        return UpsampleConvFn.apply(x, weight, bias)
+    return ConvFn.apply(upsample2x(x), weight, bias, None, 1)
 
 
 def linear(x, weight, bias=None, residual=None):

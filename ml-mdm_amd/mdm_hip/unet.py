@@ -288,7 +288,7 @@ class ResNetBlock(nn.Module):
             x = ops.conv(x, self.resample.weight, self.resample.bias, stride=2)
             activations.append(x)
         elif self.upsample_output:
-            x = ops.conv(ops.upsample2x(x), self.resample.weight, self.resample.bias)
+            x = ops.upsample_conv(x, self.resample.weight, self.resample.bias)
             activations.append(x)
         return (x, activations) if return_activations else x
 

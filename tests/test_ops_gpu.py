@@ -101,6 +101,56 @@ def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
     assert relerr(nchw(rd.grad), res.grad) < tol
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 256, 256), (3, 8, 16, 512, 256), (2, 16, 8, 768, 768)])
+def test_upsample_conv_sub_pixel_form(N, H, W, Cin, Cout):
+    """conv3x3(upsample2x(x)) computed from the low-resolution x (mdm_conv_up_fwd: per output phase a 2x2 correlation with
+    the coinciding 3x3 taps summed), its input gradient (mdm_space_to_depth2x + mdm_conv_up_dgrad) and its weight / bias
+    gradient (mdm_conv_wgrad_blocked: 16 of 36 (phase, tap) blocks, + mdm_upconv_wfold) against F.interpolate + F.conv2d
+    (reference unet.py:567-569); bf16 (fp32 and unsupported shapes take upsample2x + conv, covered by test_streaming_helpers
+    and test_conv_fwd_bwd)."""
+    from mdm_hip import ops
+
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    x = q(torch.randn(N, Cin, H, W, generator=g), dtype).requires_grad_()
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9), dtype).requires_grad_()
+    b = torch.randn(Cout, generator=g).requires_grad_()
+    y_ref = F.conv2d(F.interpolate(x, scale_factor=2), w, b, padding=1)
+    gy = q(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+    xd = nhwc(x.detach(), dtype).requires_grad_()
+    wd = w.detach().to(dev()).requires_grad_()
+    bd = b.detach().to(dev()).requires_grad_()
+    assert ops.upsample_conv_supported(xd, wd)
+    y = ops.upsample_conv(xd, wd, bd)
+    y.backward(nhwc(gy, dtype))
+    tol = TOL[dtype]
+    assert relerr(nchw(y), y_ref) < tol
+    assert relerr(nchw(xd.grad), x.grad) < tol
+    assert relerr(wd.grad, w.grad) < tol
+    assert relerr(bd.grad, b.grad) < tol
+    # ... and into a gradient arena (accumulate mode of the fold), on top of what is already there
+    class Sink:
+        def __init__(self, params):
+            self.slots = {p.data_ptr(): torch.full_like(p, 0.5) for p in params}
+        def slot(self, p):
+            return self.slots.get(p.data_ptr())
+        def ready(self, p):
+            pass
+    sink = Sink([wd, bd])
+    ops.set_grad_sink(sink)
+    try:
+        xd2 = nhwc(x.detach(), dtype).requires_grad_()
+        ops.upsample_conv(xd2, wd, bd).backward(nhwc(gy, dtype))
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_grad_sink(None)
+    assert relerr(sink.slots[wd.data_ptr()] - 0.5, w.grad) < tol
+    assert relerr(sink.slots[bd.data_ptr()] - 0.5, b.grad) < tol
+    assert relerr(nchw(xd2.grad), x.grad) < tol
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_padded_stem_and_head(dtype):
     """3-channel stem (input padded to a chunk) and 3-channel head (output padded)."""
@@ -339,9 +389,13 @@ def _attn_ref(qkv, kvc, mask, heads):
     (2, 200, 20, 4, 96, True),        # ragged L (last tile partial), ragged S
     (2, 72, 64, 2, 128, False),       # d = 128, a full text tile, L barely over one tile
     (2, 136, 0, 2, 96, False),        # no cross attention, second 128-key / 128-query pass partial
+    (40, 64, 8, 8, 32, True),         # B * H = 320 blocks: more heads than CUs (second round of blocks)
 ])
-def test_attention(dtype, B, L, S, H, d, masked):
+def test_attention(dtype, B, L, S, H, d, masked, monkeypatch):
     from mdm_hip import ops
+
+    # the library picks the one-block-per-head backward only when B * H fills the chip: force it for the small cases
+    monkeypatch.setenv("MDM_HIP_ATTN_BWD", "small")
 
     g = torch.Generator().manual_seed(6)
     C = H * d
@@ -369,6 +423,15 @@ def test_attention(dtype, B, L, S, H, d, masked):
     assert relerr(qd.grad.float().cpu(), qkv.grad) < tol
     if S:
         assert relerr(kd.grad.float().cpu(), kvc.grad) < tol
+    if dtype == torch.bfloat16 and L <= 256 and S <= 64:
+        # ... and the two streaming kernels on the same case: both backward paths must agree with the reference
+        monkeypatch.setenv("MDM_HIP_ATTN_BWD", "split")
+        qd2 = qkv.detach().to(dtype).to(dev()).requires_grad_()
+        kd2 = kvc.detach().to(dtype).to(dev()).requires_grad_() if S else None
+        ops.attention(qd2, kd2, md, H).backward(go.to(dtype).to(dev()))
+        assert relerr(qd2.grad.float().cpu(), qkv.grad) < tol
+        if S:
+            assert relerr(kd2.grad.float().cpu(), kvc.grad) < tol
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
