@@ -98,6 +98,15 @@ int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float* bias, cons
  *                         dW (Cout, Cin, 3, 3) (+)=, dbias (+)=: the split GEMM over x and dyb computes only the 16 needed
  *                         (phase, tap) blocks of dwb (4 Cout, Cin, 3, 3); the fold adds them into the 3x3 taps.
  *                         ws as mdm_conv_wgrad_plan(N H W, 4 Cout, 9 Cin).  Cin % 256 == 0, Cout % 256 == 0, H / W powers of 2. */
+/* mdm_conv_fwd_gn (ABI 3): convolution (1x1 or 3x3, stride 1) + bias (+ residual) AND the GroupNorm of its output in
+ *   ONE launch: y as mdm_conv_fwd, plus y_norm = act(GroupNorm(y)), stats [N][G][2], coef [N][Cout][2] -- exactly what
+ *   mdm_gn_fwd would produce from y (gn_act: 0 none, 1 SiLU).  Replaces nn.Conv2d followed by nn.GroupNorm where a
+ *   256-row tile is one sample (16x16 images) and a 192-column tile 8 whole groups of 24 channels (unet.py:310-311
+ *   proj_out -> ffn[0]; the last conv of a layer -> the next layer's first norm).  mdm_conv_fwd_gn_ok (host-only) tells. */
+int mdm_conv_fwd_gn_ok(int N, int H, int W, int Cin, int Cout, int ksize, int kblock, int groups, int dtype);
+int mdm_conv_fwd_gn(const void* x, const void* w_packed, const float* bias, const void* res, void* y, int N, int H, int W,
+                    int Cin, int Cout, int ksize, int kblock, const float* gamma, const float* beta, int groups, float eps,
+                    int gn_act, void* y_norm, float* stats, float* coef, int dtype, void* stream);
 int mdm_conv_s2_dgrad(const void* dy, const void* w_sel, void* dx, int N, int Ho, int Wo, int Cout, int Cin, int dtype,
                       void* stream);
 int mdm_upconv_pack(const float* w_oihw, void* w_ph, void* w_t, int Cout, int Cin, void* stream);

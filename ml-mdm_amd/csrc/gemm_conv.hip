@@ -58,6 +58,17 @@ struct ConvArgs {
   // pixel-shuffled store (ps_cout > 0): output column (phase, co), row (n, bh, bw) of a ps_H x ps_W grid goes to
   // y[n, 2 bh + ph, 2 bw + pw, co] of a [N, 2 ps_H, 2 ps_W, ps_cout] tensor (a column tile lies inside one phase)
   int ps_cout, ps_H, ps_W;
+  // GroupNorm of the OUTPUT fused into the epilogue (gn_y != null; 256x192 tile, bf16): a row tile is the 256 pixels of
+  // one sample and a column tile 8 whole groups of 24 channels, so the tile holds everything the statistics need.
+  // Besides y the launch writes gn_y = act(GroupNorm(y)), the norm's stats [N][G][2] and coef [N][C][2] (what
+  // mdm_gn_fwd would have produced from y: the standalone norm kernel and its read of y disappear).
+  void* gn_y;
+  const float* gn_gamma;
+  const float* gn_beta;
+  float* gn_stats;
+  float* gn_coef;
+  float gn_eps;
+  int gn_act, gn_groups;
 };
 
 enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };
@@ -86,7 +97,7 @@ struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 
 // `after_lds` runs once every wave is done with the LDS (the staged tile is in registers by then): a persistent
 // kernel issues the next tile's first LDS-DMA there, so those loads overlap this tile's stores.
-template <typename T, int BM, int BN, int WM, int WN, int LDS_BYTES, typename AfterLds = NoPrefetch>
+template <typename T, int BM, int BN, int WM, int WN, int LDS_BYTES, typename AfterLds = NoPrefetch, bool GN = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
                                               int m0, int n0, AfterLds after_lds = AfterLds()) {
   constexpr int EPV = Tr<T>::EPV;
@@ -171,6 +182,112 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
     }
     __syncthreads();   // the LDS is free again
     after_lds();
+    if constexpr (GN && BM == 256 && BN == 192 && sizeof(T) == 2) {
+      {
+        // ---- epilogue with the GroupNorm of the output (host-checked: whole tiles, no activation on y itself) ----
+        constexpr int NG = 8, CPG = 24;                         // groups per column tile, channels per group
+        float* const gsum = reinterpret_cast<float*>(smem + LDS_BYTES);   // scratch behind the k-loop stages:
+        float* const gsq = gsum + NG * 16;                       //   [NG][16] partial sums, partial squares,
+        float* const gmean = gsq + NG * 16;                      //   [NG] mean, [NG] rstd,
+        float* const grstd = gmean + NG;                         //   [192][2] coefficients a, b
+        float* const cab = grstd + NG;
+        if (tid < 2 * NG * 16) gsum[tid] = 0.f;
+        float part[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) part[g] = 0.f;
+        // pass 1: finish y (residual), store it, keep the ROUNDED values (what a separate norm kernel would read)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int idx = tid + i * NT_;
+          const int row = idx / OCH, ch = idx - row * OCH;
+          const size_t o = (size_t)(m0 + row) * p.Cout + n0 + ch * EPV;
+          Chunk<T> c;
+          c.load(reinterpret_cast<const T*>(&raw[i]));
+          if (R) {
+            Chunk<T> rr;
+            rr.load(reinterpret_cast<const T*>(&pre[i]));
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) c.v[e] += rr.v[e];
+            c.store(reinterpret_cast<T*>(&raw[i]));
+            c.load(reinterpret_cast<const T*>(&raw[i]));
+          }
+          *reinterpret_cast<uint4*>(Y + o) = raw[i];
+          float sv = 0.f;
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) sv += c.v[e];
+          const int g = ch / 3;
+#pragma unroll
+          for (int gg = 0; gg < NG; ++gg) part[gg] += g == gg ? sv : 0.f;
+        }
+        __syncthreads();   // scratch zeroed
+#pragma unroll
+        for (int gg = 0; gg < NG; ++gg) atomicAdd(&gsum[gg * 16 + (lane & 15)], part[gg]);
+        __syncthreads();
+        if (tid < NG) {
+          float t = 0.f;
+          for (int k = 0; k < 16; ++k) t += gsum[tid * 16 + k];
+          gmean[tid] = t / (float)(BM * CPG);
+        }
+        __syncthreads();
+        // pass 2: centred squares
+#pragma unroll
+        for (int g = 0; g < NG; ++g) part[g] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int ch = (tid + i * NT_) % OCH;
+          Chunk<T> c;
+          c.load(reinterpret_cast<const T*>(&raw[i]));
+          const int g = ch / 3;
+          const float mu = gmean[g];
+          float sv = 0.f;
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) { const float d = c.v[e] - mu; sv += d * d; }
+#pragma unroll
+          for (int gg = 0; gg < NG; ++gg) part[gg] += g == gg ? sv : 0.f;
+        }
+#pragma unroll
+        for (int gg = 0; gg < NG; ++gg) atomicAdd(&gsq[gg * 16 + (lane & 15)], part[gg]);
+        __syncthreads();
+        const int img = m0 / BM;                                // the sample this row tile is
+        if (tid < NG) {
+          float t = 0.f;
+          for (int k = 0; k < 16; ++k) t += gsq[tid * 16 + k];
+          const float rstd = rsqrtf(t / (float)(BM * CPG) + p.gn_eps);
+          grstd[tid] = rstd;
+          const int g = n0 / CPG + tid;
+          p.gn_stats[((size_t)img * p.gn_groups + g) * 2] = gmean[tid];
+          p.gn_stats[((size_t)img * p.gn_groups + g) * 2 + 1] = rstd;
+        }
+        __syncthreads();
+        if (tid < BN) {
+          const int cglob = n0 + tid, g = tid / CPG;
+          const float ga = p.gn_gamma[cglob], be = p.gn_beta[cglob];
+          const float a_ = ga * grstd[g], b_ = be - gmean[g] * grstd[g] * ga;
+          cab[2 * tid] = a_; cab[2 * tid + 1] = b_;
+          p.gn_coef[((size_t)img * p.Cout + cglob) * 2] = a_;
+          p.gn_coef[((size_t)img * p.Cout + cglob) * 2 + 1] = b_;
+        }
+        __syncthreads();
+        // pass 3: the normalised output
+        T* __restrict__ Y2 = reinterpret_cast<T*>(p.gn_y);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int idx = tid + i * NT_;
+          const int row = idx / OCH, ch = idx - row * OCH;
+          const size_t o = (size_t)(m0 + row) * p.Cout + n0 + ch * EPV;
+          Chunk<T> c;
+          c.load(reinterpret_cast<const T*>(&raw[i]));
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) {
+            const float z = cab[2 * (ch * EPV + e)] * c.v[e] + cab[2 * (ch * EPV + e) + 1];
+            c.v[e] = p.gn_act ? silu_f(z) : z;
+          }
+          c.store(Y2 + o);
+        }
+        __syncthreads();   // the scratch may be zeroed again by the next tile's epilogue
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int idx = tid + i * NT_;
@@ -419,7 +536,9 @@ struct NoConvGroup {};
 // channel block: k-tile kt = (channel block kt >> 2, tap 4 + (kt & 1) + 3 * ((kt >> 1) & 1)), K = 4 * Cin.  That is the
 // input gradient of a STRIDE-2 3x3 convolution in its pixel-unshuffled form (mdm_conv_s2_dgrad): dx[2b + p] only draws
 // from dy[b] and dy[b + 1], so over the 2x2-blocked dx (4 Cin channels per block) it is a 2x2 stride-1 correlation.
-template <int BM, int BN, int WM, int WN, int MODE, bool GROUPED = false, bool SPLITK = false, bool SEL4 = false>
+// GN: the epilogue also normalises the output (ConvArgs::gn_*; its own instantiation, so the extra registers of that
+// epilogue do not touch the other kernels' allocation).
+template <int BM, int BN, int WM, int WN, int MODE, bool GROUPED = false, bool SPLITK = false, bool SEL4 = false, bool GN = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs p, std::conditional_t<GROUPED, ConvGroup, NoConvGroup> gr) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type has no host-side counterpart: the host pass only needs the stub
   using T = bf16;
@@ -648,12 +767,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
     } else {
       ConvArgs pe = p;   // the epilogue's view of this tile's problem (the prefetch below already moves on to the next)
       if constexpr (GROUPED) { pe.bias = gr.bias[grp]; pe.y = gr.y[grp]; }
-      conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE>(pe, acc, smem, cur_m0, cur_n0, [&]() {
+      auto prefetch_next = [&]() {
         if (next < tiles_total) {
           MDM_TILE_SETUP(next);
           MDM_TILE_PROLOGUE();
         }
-      });
+      };
+      conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE, decltype(prefetch_next), GN>(pe, acc, smem, cur_m0, cur_n0, prefetch_next);
     }
     if (next >= tiles_total) break;
     tile = next;
@@ -1901,6 +2021,19 @@ static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
   MDM_LAUNCH_STATUS();
 }
 
+template <int MODE>
+static int launch_conv_bl_gn(const ConvArgs& a, hipStream_t st) {
+  constexpr int BM = 256, BN = 192, WM = 2, WN = 4;
+  constexpr int smem = 2 * (BM + BN) * 128 + 4096;   // + the epilogue's statistics scratch
+  auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE, false, false, false, true>;
+  ensure_dynamic_lds(kern, smem);
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+  const int resident = device_cus();
+  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a, NoConvGroup{});
+  MDM_NOTE_KERNEL("conv_gemm_bl_kernel<%d, %d, %d, %d, %d, +gn>", BM, BN, WM, WN, MODE);
+  MDM_LAUNCH_STATUS();
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_conv_bl_sel4(const ConvArgs& a, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
@@ -2162,6 +2295,36 @@ extern "C" int mdm_conv_up_dgrad(const void* dyb, const void* w_t, void* dx, int
   MDM_CHECK_ARG((conv_bl_ok<bf16, MODE_3x3>(a)));
   const int code = conv_tile_code(a.M, a.Cout, DT_BF16);
   return launch_sel4(a, code == 256256 ? 256 : (code == 256192 ? 192 : 128), reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- convolution + GroupNorm of its output in one launch ------------------------------------------------------
+// host-only: does (problem, norm) fit the fused epilogue?  bf16; 16x16 images (a 256-row tile = one sample); 24 channels
+// per group and Cout a multiple of 192 (a 192-column tile = 8 whole groups); a problem the buffer-addressed loader takes
+extern "C" int mdm_conv_fwd_gn_ok(int N, int H, int W, int Cin, int Cout, int ksize, int kblock, int groups, int dtype) {
+  if (dtype != DT_BF16 || H * W != 256 || Cout % 192 != 0 || groups <= 0 || Cout != groups * 24 || Cin % 64 != 0) return 0;
+  if (ksize != 1 && !(ksize == 3 && kblock == 64)) return 0;
+  ConvArgs a = {};
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K = ksize * ksize * Cin; a.kblk = kblock;
+  return (ksize == 1 ? conv_bl_ok<bf16, MODE_1x1>(a) : conv_bl_ok<bf16, MODE_3x3>(a)) ? 1 : 0;
+}
+
+// y = conv(x, w_packed) + bias (+ res)  AND  y_norm = act(GroupNorm(y; gamma, beta, groups, eps)), stats [N][G][2],
+// coef [N][Cout][2] (the outputs of mdm_gn_fwd on y) from ONE launch -- replaces nn.Conv2d followed by nn.GroupNorm
+// (models/unet.py:310-311 proj_out -> ffn[0]; :312 -> the next layer's norm; :238 -> :300).  stride 1, no activation on y.
+extern "C" int mdm_conv_fwd_gn(const void* x, const void* w_packed, const float* bias, const void* res, void* y, int N, int H,
+                               int W, int Cin, int Cout, int ksize, int kblock, const float* gamma, const float* beta,
+                               int groups, float eps, int gn_act, void* y_norm, float* stats, float* coef, int dtype,
+                               void* stream) {
+  MDM_CHECK_ARG(x && w_packed && y && gamma && beta && y_norm && stats && coef);
+  MDM_CHECK_ARG(mdm_conv_fwd_gn_ok(N, H, W, Cin, Cout, ksize, kblock, groups, dtype));
+  ConvArgs a = {};
+  a.x = x; a.w = w_packed; a.bias = bias; a.res = res; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = H; a.Wo = W; a.Cout = Cout; a.stride = 1;
+  a.M = N * H * W; a.K = ksize * ksize * Cin; a.kblk = kblock; a.ksplit = 1;
+  a.gn_y = y_norm; a.gn_gamma = gamma; a.gn_beta = beta; a.gn_stats = stats; a.gn_coef = coef; a.gn_eps = eps;
+  a.gn_act = gn_act; a.gn_groups = groups;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return ksize == 1 ? launch_conv_bl_gn<MODE_1x1>(a, st) : launch_conv_bl_gn<MODE_3x3>(a, st);
 }
 
 // y[g] [M, Cout] = x[g] [M, Cin] * w_packed[g]^T + bias[g] for `groups` (<= 32) linear layers of one shape, bf16, in ONE

@@ -633,59 +633,128 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, bias = ctx.saved_tensors
-        dy = _c(dy)
-        ks, stride = ctx.ks, ctx.stride
-        wf, wd, bp, cin_pad, cout_pad, kbf, kbd = packed_weight(weight, bias, x.dtype)
-        cout, cin = weight.shape[0], weight.shape[1]
-        N, H, W, Ho, Wo = _geom(x, ks, stride)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            if wd is None:
-                raise _lib.MdmHipError("input gradient requested for a channel-padded convolution")
-            dx = torch.empty_like(x)
-            if ks == 3 and stride == 2 and x.dtype == torch.bfloat16 and cout_pad == cout and cout % 64 == 0 and cin % 128 == 0 \
-                    and H % 2 == 0 and W % 2 == 0:
-                # sub-pixel form: a 2x2 correlation over dy per phase of dx, stored pixel-shuffled (mdm_conv_s2_dgrad)
-                wsel = packed_s2_dgrad_weight(weight)
-                _prof_wrap("conv_gemm_bl_kernel<sel4> (3x3 stride-2 input gradient) M=%d N=%d K=%d" % (N * Ho * Wo, 4 * cin, 4 * cout),
-                           2.0 * N * Ho * Wo * cout * 9 * cin, lambda: _lib.check(
-                    _lib.lib().mdm_conv_s2_dgrad(_p(dy), _p(wsel), _p(dx), N, Ho, Wo, cout, cin, BF16, _stream()), "mdm_conv_s2_dgrad"))
-            elif ks == 3 and stride == 2:
-                _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, 3, 1, 1, 0, kbd)
-            else:
-                _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, ks, 1, 0, 0, kbd)
-        padded = cout_pad != cout or cin_pad != cin
-        want_b = bias is not None and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            slot = None if padded else _slot(weight)
-            bslot = _slot(bias) if (slot is not None and want_b) else None
-            if slot is not None:
-                # weight (and, when it also lives in the arena, bias) gradient from one launch
-                _wgrad_into_sink(x, dy, weight, bias, slot, bslot, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride)
-                if bslot is not None:
-                    want_b = False
-            else:
-                dbt = torch.empty(cout_pad, dtype=torch.float32, device=x.device) if want_b else None
-                dwp = _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, dbias=dbt)
-                if padded:
-                    dwp = dwp[:cout, :cin].contiguous()
-                dw = dwp.view(weight.shape)
-                if want_b:
-                    db = dbt[:cout]
-                    want_b = False
-        if want_b:
-            slot = None if cout_pad != cout else _slot(bias)
-            if slot is not None:
-                _colsum_launch(dy, N * Ho * Wo, cout_pad, out=slot)
-                _grad_sink.ready(bias)
-            else:
-                db = _colsum_launch(dy, N * Ho * Wo, cout_pad)[:cout]
-        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dres, None
+        return _conv_backward(ctx, x, weight, bias, dy) + (None,)
+
+
+def _conv_backward(ctx, x, weight, bias, dy):
+    """input / weight / bias / residual gradients of y = conv(x, weight) + bias (+ residual); ``ctx`` carries ks, stride,
+    has_res and needs_input_grad[0:4] = (x, weight, bias, residual).  -> (dx, dw, db, dres)"""
+    dy = _c(dy)
+    ks, stride = ctx.ks, ctx.stride
+    wf, wd, bp, cin_pad, cout_pad, kbf, kbd = packed_weight(weight, bias, x.dtype)
+    cout, cin = weight.shape[0], weight.shape[1]
+    N, H, W, Ho, Wo = _geom(x, ks, stride)
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        if wd is None:
+            raise _lib.MdmHipError("input gradient requested for a channel-padded convolution")
+        dx = torch.empty_like(x)
+        if ks == 3 and stride == 2 and x.dtype == torch.bfloat16 and cout_pad == cout and cout % 64 == 0 and cin % 128 == 0 \
+                and H % 2 == 0 and W % 2 == 0:
+            # sub-pixel form: a 2x2 correlation over dy per phase of dx, stored pixel-shuffled (mdm_conv_s2_dgrad)
+            wsel = packed_s2_dgrad_weight(weight)
+            _prof_wrap("conv_gemm_bl_kernel<sel4> (3x3 stride-2 input gradient) M=%d N=%d K=%d" % (N * Ho * Wo, 4 * cin, 4 * cout),
+                       2.0 * N * Ho * Wo * cout * 9 * cin, lambda: _lib.check(
+                _lib.lib().mdm_conv_s2_dgrad(_p(dy), _p(wsel), _p(dx), N, Ho, Wo, cout, cin, BF16, _stream()), "mdm_conv_s2_dgrad"))
+        elif ks == 3 and stride == 2:
+            _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, 3, 1, 1, 0, kbd)
+        else:
+            _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, ks, 1, 0, 0, kbd)
+    padded = cout_pad != cout or cin_pad != cin
+    want_b = bias is not None and ctx.needs_input_grad[2]
+    if ctx.needs_input_grad[1]:
+        slot = None if padded else _slot(weight)
+        bslot = _slot(bias) if (slot is not None and want_b) else None
+        if slot is not None:
+            # weight (and, when it also lives in the arena, bias) gradient from one launch
+            _wgrad_into_sink(x, dy, weight, bias, slot, bslot, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride)
+            if bslot is not None:
+                want_b = False
+        else:
+            dbt = torch.empty(cout_pad, dtype=torch.float32, device=x.device) if want_b else None
+            dwp = _wgrad_launch(x, dy, N, H, W, cin_pad, Ho, Wo, cout_pad, ks, stride, dbias=dbt)
+            if padded:
+                dwp = dwp[:cout, :cin].contiguous()
+            dw = dwp.view(weight.shape)
+            if want_b:
+                db = dbt[:cout]
+                want_b = False
+    if want_b:
+        slot = None if cout_pad != cout else _slot(bias)
+        if slot is not None:
+            _colsum_launch(dy, N * Ho * Wo, cout_pad, out=slot)
+            _grad_sink.ready(bias)
+        else:
+            db = _colsum_launch(dy, N * Ho * Wo, cout_pad)[:cout]
+    dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+    return dx, dw, db, dres
 
 
 def conv(x, weight, bias=None, residual=None, stride=1):
     return ConvFn.apply(x, weight, bias, residual, stride)
+
+
+# --------------------------------------------------------------------------------------
+# convolution + the GroupNorm that reads its output, one launch
+# --------------------------------------------------------------------------------------
+def conv_gn_enabled():
+    """whether the model uses the fused launch where it applies.  Off unless MDM_HIP_CONV_GN=1: measured in one call
+    against conv + group_norm on the 64x64 U-Net step (profiles/r03_did_not_pay.md) it is neutral -- the norm kernel it
+    removes is an HBM-bound launch that already overlaps the weight-gradient stream, and the epilogue's three passes over
+    the staged tile cost the convolution what the norm cost."""
+    return os.environ.get("MDM_HIP_CONV_GN", "0") == "1"
+
+
+def conv_gn_supported(x, weight, gamma, groups, stride=1):
+    """the fused epilogue takes bf16 16x16 images with 24 channels per group (the 768-channel level of the 64x64 U-Net)"""
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.dim() != 4 or stride != 1:
+        return False
+    ks = weight.shape[2] if weight.dim() == 4 else 1
+    cin, cout = weight.shape[1], weight.shape[0]
+    kb = 64 if (ks == 3 and cin % 64 == 0) else 0
+    return bool(_lib.lib().mdm_conv_fwd_gn_ok(x.shape[0], x.shape[1], x.shape[2], cin, cout, ks, kb, groups, BF16)) and \
+        gamma.numel() == cout
+
+
+class ConvGNFn(torch.autograd.Function):
+    """(y, y_norm) with y = conv(x, weight) + bias (+ residual) and y_norm = act(GroupNorm(y; gamma, beta)): the norm's
+    statistics and its normalised output come out of the convolution's epilogue (C ABI mdm_conv_fwd_gn) -- the separate
+    norm kernel and its read of y are gone.  Backward = the GroupNorm backward kernel (the gradient that reaches y
+    directly -- the residual branch, a skip connection -- rides in as its ``dres``) followed by the convolution's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, gamma, beta, groups, eps, act):
+        _require_gpu(x)
+        x, residual = _c(x), _c(residual)
+        ks = weight.shape[2] if weight.dim() == 4 else 1
+        wf, wd, bp, cin_pad, cout_pad, kbf, kbd = packed_weight(weight, bias, x.dtype)
+        N, H, W = x.shape[0], x.shape[1], x.shape[2]
+        g32, b32 = _c(gamma.detach().float()), _c(beta.detach().float())
+        y = torch.empty((N, H, W, cout_pad), dtype=x.dtype, device=x.device)
+        yn = torch.empty_like(y)
+        stats = torch.empty((N, groups, 2), dtype=torch.float32, device=x.device)
+        coef = torch.empty((N, cout_pad, 2), dtype=torch.float32, device=x.device)
+        _prof_wrap("conv_gemm_bl_kernel<256, 192, +gn> M=%d N=%d K=%d" % (N * H * W, cout_pad, ks * ks * cin_pad),
+                   2.0 * N * H * W * cout_pad * ks * ks * cin_pad, lambda: _lib.check(
+            _lib.lib().mdm_conv_fwd_gn(_p(x), _p(wf), _p(bp), _p(residual), _p(y), N, H, W, cin_pad, cout_pad, ks, kbf, _p(g32), _p(b32),
+                                       groups, float(eps), act, _p(yn), _p(stats), _p(coef), BF16, _stream()), "mdm_conv_fwd_gn"))
+        ctx.save_for_backward(x, weight, bias, y, gamma, beta, stats, coef)
+        ctx.ks, ctx.stride, ctx.has_res = ks, 1, residual is not None
+        ctx.groups, ctx.act = groups, act
+        return y, yn
+
+    @staticmethod
+    def backward(ctx, dy_direct, dyn):
+        x, weight, bias, y, gamma, beta, stats, coef = ctx.saved_tensors
+        # gradient w.r.t. y: through the norm (dyn) plus whatever reached y directly
+        dy, dgamma, dbeta, _ = _gn_backward(dyn, y, gamma, beta, None, stats, coef, dy_direct, None, ctx.groups, ctx.act)
+        dx, dw, db, dres = _conv_backward(ctx, x, weight, bias, dy)
+        return dx, dw, db, dres, dgamma, dbeta, None, None, None
+
+
+def conv_gn(x, weight, bias, residual, gamma, beta, groups, eps=1e-5, silu=False):
+    """-> (y, act(GroupNorm(y))) with y = conv(x) + bias (+ residual); see ConvGNFn / conv_gn_supported"""
+    return ConvGNFn.apply(x, weight, bias, residual, gamma, beta, groups, eps, 1 if silu else 0)
 
 
 # --------------------------------------------------------------------------------------
@@ -901,42 +970,49 @@ class GroupNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dres=None, dres2=None):
         x, gamma, beta, film, stats, coef = ctx.saved_tensors
-        dy = _c(dy)
-        dres = _c(dres) if dres is not None else None
-        dres2 = _c(dres2) if dres2 is not None else None
-        if dres is None and dres2 is not None:
-            dres, dres2 = dres2, None
-        N, C = x.shape[0], x.shape[-1]
-        HW = x.numel() // (N * C)
-        g32, b32 = _c(gamma.detach().float()), _c(beta.detach().float())
-        dx = torch.empty_like(x)
-        sg, sb = _slot(gamma), _slot(beta)
-        sunk = sg is not None and sb is not None
-        deferred = sunk and _defer_wgrad   # per-sample rows now, one multi-layer reduce at the next flush point
-        if deferred:
-            dgamma, dbeta = _gn_rows(N, C, x.device)
-        else:
-            dgamma = sg if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
-            dbeta = sb if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
-        dfilm = torch.empty_like(film) if film is not None else None
-        ws = _gn_ws(N, HW, C, ctx.groups, x.device)
-        mode = 2 if deferred else (1 if sunk else 0)
-        npass = 3.0 + (dres is not None) + (dres2 is not None)
-        _prof_wrap("group_norm bwd (HW=%d)" % HW, npass * x.numel() * x.element_size(), lambda: _lib.check(
-            _lib.lib().mdm_gn_bwd(_p(dy), _p(x), _p(g32), _p(b32), _p(film), _p(stats), _p(coef), _p(dres), _p(dres2), _p(dx), _p(dgamma),
-                                  _p(dbeta), _p(dfilm), _p(ws), N, HW, C, ctx.groups, ctx.act, mode, _dt(x), _stream()),
-            "mdm_gn_bwd",
-        ), kind="hbm")
-        if deferred:
-            _gn_pending.append((dgamma, dbeta, sg, sb, N, C, gamma, beta))
-            _sink_defer(gamma)
-            _sink_defer(beta)
-            return dx, None, None, dfilm, None, None, None, None
-        if sunk:
-            _grad_sink.ready(gamma)
-            _grad_sink.ready(beta)
-            return dx, None, None, dfilm, None, None, None, None
+        dx, dgamma, dbeta, dfilm = _gn_backward(dy, x, gamma, beta, film, stats, coef, dres, dres2, ctx.groups, ctx.act)
         return dx, dgamma, dbeta, dfilm, None, None, None, None
+
+
+def _gn_backward(dy, x, gamma, beta, film, stats, coef, dres, dres2, groups, act):
+    """the GroupNorm backward launch (+ where its parameter gradients go): -> (dx, dgamma, dbeta, dfilm); dgamma / dbeta
+    are None when they went into the gradient sink (now, or as per-sample rows reduced at the next flush point)"""
+    dy = _c(dy)
+    dres = _c(dres) if dres is not None else None
+    dres2 = _c(dres2) if dres2 is not None else None
+    if dres is None and dres2 is not None:
+        dres, dres2 = dres2, None
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    g32, b32 = _c(gamma.detach().float()), _c(beta.detach().float())
+    dx = torch.empty_like(x)
+    sg, sb = _slot(gamma), _slot(beta)
+    sunk = sg is not None and sb is not None
+    deferred = sunk and _defer_wgrad   # per-sample rows now, one multi-layer reduce at the next flush point
+    if deferred:
+        dgamma, dbeta = _gn_rows(N, C, x.device)
+    else:
+        dgamma = sg if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = sb if sunk else torch.empty(C, dtype=torch.float32, device=x.device)
+    dfilm = torch.empty_like(film) if film is not None else None
+    ws = _gn_ws(N, HW, C, groups, x.device)
+    mode = 2 if deferred else (1 if sunk else 0)
+    npass = 3.0 + (dres is not None) + (dres2 is not None)
+    _prof_wrap("group_norm bwd (HW=%d)" % HW, npass * x.numel() * x.element_size(), lambda: _lib.check(
+        _lib.lib().mdm_gn_bwd(_p(dy), _p(x), _p(g32), _p(b32), _p(film), _p(stats), _p(coef), _p(dres), _p(dres2), _p(dx), _p(dgamma),
+                              _p(dbeta), _p(dfilm), _p(ws), N, HW, C, groups, act, mode, _dt(x), _stream()),
+        "mdm_gn_bwd",
+    ), kind="hbm")
+    if deferred:
+        _gn_pending.append((dgamma, dbeta, sg, sb, N, C, gamma, beta))
+        _sink_defer(gamma)
+        _sink_defer(beta)
+        return dx, None, None, dfilm
+    if sunk:
+        _grad_sink.ready(gamma)
+        _grad_sink.ready(beta)
+        return dx, None, None, dfilm
+    return dx, dgamma, dbeta, dfilm
 
 
 def group_norm(x, gamma, beta, groups, eps=1e-5, film=None, silu=False, passthrough=False):

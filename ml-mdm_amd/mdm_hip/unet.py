@@ -225,7 +225,13 @@ class SelfAttention(nn.Module):
                 cn = ops.layer_norm(raw, self.norm_cond.weight, self.norm_cond.bias, self.norm_cond.eps)
                 kvc = ops.linear(cn, self.kv_cond.weight, self.kv_cond.bias)
         a = ops.attention(qkv.reshape(N, H * W, 3 * C), kvc, cond_mask if kvc is not None else None, self.num_heads)
-        x = ops.conv(a.reshape(N, H, W, C), self.proj_out.weight, self.proj_out.bias, residual=x)
+        a = a.reshape(N, H, W, C)
+        if self.ffn is not None and ops.conv_gn_enabled() and ops.conv_gn_supported(a, self.proj_out.weight, self.ffn[0].weight, 32):
+            # proj_out and the GroupNorm that opens the FFN in one launch (the norm's statistics need exactly what a
+            # 256-pixel x 8-group output tile of the convolution holds)
+            x, fn = ops.conv_gn(a, self.proj_out.weight, self.proj_out.bias, x, self.ffn[0].weight, self.ffn[0].bias, 32, self.ffn[0].eps)
+            return ops.ffn(fn, self.ffn[1].weight, self.ffn[1].bias, self.ffn[3].weight, self.ffn[3].bias, residual=x)
+        x = ops.conv(a, self.proj_out.weight, self.proj_out.bias, residual=x)
         if self.ffn is not None:
             fn, x = ops.group_norm(x, self.ffn[0].weight, self.ffn[0].bias, 32, self.ffn[0].eps, passthrough=True)
             x = ops.ffn(fn, self.ffn[1].weight, self.ffn[1].bias, self.ffn[3].weight, self.ffn[3].bias, residual=x)

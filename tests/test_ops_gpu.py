@@ -151,6 +151,63 @@ def test_upsample_conv_sub_pixel_form(N, H, W, Cin, Cout):
     assert relerr(nchw(xd2.grad), x.grad) < tol
 
 
+@pytest.mark.parametrize("N,Cin,Cout,ks,silu,res", [(2, 768, 768, 1, False, True), (3, 768, 768, 3, True, True),
+                                                    (2, 1536, 768, 3, True, False), (1, 256, 768, 1, False, False)])
+def test_conv_with_group_norm_of_its_output(N, Cin, Cout, ks, silu, res):
+    """mdm_conv_fwd_gn: y = conv(x) + bias (+ residual) and act(GroupNorm(y)) from one launch (16x16 images, 32 groups of 24
+    channels), forward and every gradient -- y feeds both the norm and a second consumer, as the residual stream does
+    (reference unet.py:310-311 proj_out -> ffn[0]) -- against F.conv2d + F.group_norm."""
+    from mdm_hip import ops
+
+    dtype = torch.bfloat16
+    H = W = 16
+    g = torch.Generator().manual_seed(5)
+    x = q(torch.randn(N, Cin, H, W, generator=g), dtype).requires_grad_()
+    w = q(torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks), dtype).requires_grad_()
+    b = torch.randn(Cout, generator=g).requires_grad_()
+    r = q(torch.randn(N, Cout, H, W, generator=g), dtype).requires_grad_() if res else None
+    gamma = (1 + 0.3 * torch.randn(Cout, generator=g)).requires_grad_()
+    beta = (0.3 * torch.randn(Cout, generator=g)).requires_grad_()
+    y_ref = F.conv2d(x, w, b, padding=ks // 2)
+    if res:
+        y_ref = y_ref + r
+    yq = q(y_ref, dtype)                       # the norm reads the stored (rounded) y on both sides
+    yq = y_ref + (yq - y_ref).detach()
+    n_ref = F.group_norm(yq, 32, gamma, beta, 1e-5)
+    if silu:
+        n_ref = F.silu(n_ref)
+    gy, gn = q(torch.randn(y_ref.shape, generator=g), dtype), q(torch.randn(y_ref.shape, generator=g), dtype)
+    torch.autograd.backward([y_ref, n_ref], [gy, gn])
+    xd = nhwc(x.detach(), dtype).requires_grad_()
+    wd = w.detach().to(dev()).requires_grad_()
+    bd = b.detach().to(dev()).requires_grad_()
+    rd = nhwc(r.detach(), dtype).requires_grad_() if res else None
+    gd = gamma.detach().to(dev()).requires_grad_()
+    btd = beta.detach().to(dev()).requires_grad_()
+    assert ops.conv_gn_supported(xd, wd, gd, 32)
+    y, yn = ops.conv_gn(xd, wd, bd, rd, gd, btd, 32, 1e-5, silu=silu)
+    torch.autograd.backward([y, yn], [nhwc(gy, dtype), nhwc(gn, dtype)])
+    tol = TOL[dtype]
+    assert relerr(nchw(y), y_ref) < tol
+    assert relerr(nchw(yn), n_ref) < tol
+    assert relerr(nchw(xd.grad), x.grad) < tol
+    assert relerr(wd.grad, w.grad) < tol
+    assert relerr(bd.grad, b.grad) < tol
+    assert relerr(gd.grad, gamma.grad) < tol
+    assert relerr(btd.grad, beta.grad) < tol
+    if res:
+        assert relerr(nchw(rd.grad), r.grad) < tol
+    # identical to the two-launch path (conv, then group_norm with the pass-through) up to the rounding of y
+    xs = nhwc(x.detach(), dtype)
+    y2 = ops.conv(xs, wd.detach(), bd.detach(), residual=rd.detach() if res else None)
+    n2 = ops.group_norm(y2, gd.detach(), btd.detach(), 32, 1e-5, silu=silu)
+    assert relerr(y2, y.detach()) < 8e-3       # one bf16 ulp: the unfused launch may pick another tile / accumulation order
+    assert relerr(n2, yn.detach()) < 2e-2
+    # shapes the fused epilogue does not take
+    assert not ops.conv_gn_supported(nhwc(torch.randn(2, 768, 32, 32), dtype), wd, gd, 32)
+    assert not ops.conv_gn_supported(nhwc(torch.randn(2, Cin, 16, 16), torch.float32), wd, gd, 32)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_padded_stem_and_head(dtype):
     """3-channel stem (input padded to a chunk) and 3-channel head (output padded)."""

@@ -222,8 +222,9 @@ def main():
             _lib.check(_lib.lib().mdm_gn_fwd(ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(yy), ops._p(stats), ops._p(coef), ops._p(ws), B, H * H, C, 32, 1e-5, 1, ops._dt(xd), ops._stream()), "fwd")
             gmode = int(os.environ.get('KB_GN_MODE', '2'))   # 2: per-sample rows (deferred reduce), 1: atomics into a slot
             dxx = torch.empty_like(xd); dg = torch.zeros(B if gmode == 2 else 1, C, device=dev); db = torch.zeros_like(dg)
+            dres = torch.randn_like(xd) if os.environ.get('KB_GN_RES') else None   # + the residual-branch gradient (as in the model)
             def direct():
-                _lib.check(_lib.lib().mdm_gn_bwd(ops._p(gy), ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(stats), ops._p(coef), None, None, ops._p(dxx), ops._p(dg), ops._p(db), None, ops._p(ws), B, H * H, C, 32, 1, gmode, ops._dt(xd), ops._stream()), "bwd")
+                _lib.check(_lib.lib().mdm_gn_bwd(ops._p(gy), ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(stats), ops._p(coef), ops._p(dres), None, ops._p(dxx), ops._p(dg), ops._p(db), None, ops._p(ws), B, H * H, C, 32, 1, gmode, ops._dt(xd), ops._stream()), "bwd")
             def directf():
                 _lib.check(_lib.lib().mdm_gn_fwd(ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(yy), ops._p(stats), ops._p(coef), ops._p(ws), B, H * H, C, 32, 1e-5, 1, ops._dt(xd), ops._stream()), "fwd")
             for f in (direct, directf):
@@ -236,7 +237,7 @@ def main():
             e2.record()
             torch.cuda.synchronize()
             tb, t = e0.elapsed_time(e1) / 50e3, e1.elapsed_time(e2) / 50e3
-            print("gn %dx%d C=%-5d (%6.1f MB)  fwd %7.3f ms %6.0f GB/s   bwd %7.3f ms %6.0f GB/s" % (H, H, C, nb / 1e6, t * 1e3, 2 * nb / t / 1e9, tb * 1e3, 3 * nb / tb / 1e9), flush=True)
+            print("gn %dx%d C=%-5d (%6.1f MB)  fwd %7.3f ms %6.0f GB/s   bwd %7.3f ms %6.0f GB/s" % (H, H, C, nb / 1e6, t * 1e3, 2 * nb / t / 1e9, tb * 1e3, (4 if dres is not None else 3) * nb / tb / 1e9), flush=True)
     if what in ("attn", "all"):
         for L, d in ((1024, 64), (256, 96)):
             C = 8 * d
