@@ -2073,11 +2073,14 @@ static bool conv_bl_ok(const ConvArgs& a) {
 // gives 48 tiles of 128x128, each walking all 108 k-tiles of a 3x3 768 -> 768 convolution -- 73 us for 15 us of work).
 // Splits: enough blocks for two per CU, at least 6 k-tiles each, at most 16, and only when the split saves at least 16
 // k-tiles of serial walk (~10 us) -- the second launch costs about that much.  1 = do not split.
+// Considered whenever the tiles fill less than `fill` percent of the 2-per-CU slots: 80 also catches the training shapes
+// of the nested model's inner U-Net at batch 16 (M = 4096: 192 tiles of 128x128 at N = 768), 25 was the sampling-only rule.
 static int conv_ksplit(int M, int Cout, int K, int dtype) {
   if (dtype != DT_BF16 || K % 64 != 0 || Cout % 8 != 0 || Cout <= 64) return 1;
+  static const int fill = getenv("MDM_HIP_SPLIT_FILL") ? atoi(getenv("MDM_HIP_SPLIT_FILL")) : 80;
   const long tiles = (long)((M + 127) / 128) * ((Cout + 127) / 128);
   const int nt = K / 64, cus = device_cus();
-  if (tiles * 2 > cus || nt < 12) return 1;
+  if (tiles * 100 > (long)fill * 2 * cus || nt < 12) return 1;
   long sp = (2L * cus) / tiles;
   if (sp > nt / 6) sp = nt / 6;
   if (sp > 16) sp = 16;
