@@ -44,7 +44,7 @@ FWD_GFLOP_PER_SAMPLE = {"unet64": 363.9, "nested256": 589.1, "mini": 0.0}
 PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0       # HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s measured for a float4 copy)
-PMC_FILES = ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
+PMC_FILES = ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
 
 
 def build(workload, device, seed=0):
@@ -89,8 +89,11 @@ def pmc_traffic(kernel_label):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
+        # the live label ends its template list where the defaulted flags begin ("<256, 256, 2, 4, 0>" against the
+        # symbol's "<256, 256, 2, 4, 0, false, false, false, false>"): match up to the closing bracket
+        stem = kernel_label[:-1] if kernel_label.endswith(">") else kernel_label
         for k, v in json.load(open(path))["kernels"].items():
-            if kernel_label in k:
+            if kernel_label in k or (stem + ", false" in k and "true" not in k[k.find(stem):]):
                 return v["hbm_bytes_per_launch"], "profiles/" + name
     return None, None
 

@@ -89,6 +89,7 @@ int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float* bias, cons
  *   mdm_conv_s2_dgrad     dx [N, 2Ho, 2Wo, Cin] of the stride-2 conv from dy [N, Ho, Wo, Cout]; w_sel [4 Cin][Cout/64][4][64]
  *                         (row (ph, pw, ci), tap j = 2 dh + dw reads dy[b + d]; zeros where a phase has no tap).
  *                         Cout % 64 == 0, Cin % 128 == 0, even H / W.  mdm_conv_fwd(transposed = 1) stays for the rest.
+ *   mdm_s2dgrad_pack      w (Cout, Cin, 3, 3) fp32 -> that w_sel (one launch; re-run after every optimizer step).
  *   mdm_upconv_pack       w (Cout, Cin, 3, 3) fp32 -> w_ph [4 Cout][Cin/64][4][64] (forward) and w_t [Cin][4][Cout/64][4][64]
  *                         (input gradient): the 3x3 taps that fall on one low-resolution pixel of a phase, summed.
  *   mdm_conv_up_fwd       y [N, 2H, 2W, Cout] = conv3x3(upsample2x(x)) + bias from x [N, H, W, Cin]; bias4 = bias x 4 phases.
@@ -109,6 +110,7 @@ int mdm_conv_fwd_gn(const void* x, const void* w_packed, const float* bias, cons
                     int gn_act, void* y_norm, float* stats, float* coef, int dtype, void* stream);
 int mdm_conv_s2_dgrad(const void* dy, const void* w_sel, void* dx, int N, int Ho, int Wo, int Cout, int Cin, int dtype,
                       void* stream);
+int mdm_s2dgrad_pack(const float* w_oihw, void* w_sel, int Cout, int Cin, void* stream);
 int mdm_upconv_pack(const float* w_oihw, void* w_ph, void* w_t, int Cout, int Cin, void* stream);
 int mdm_conv_up_fwd(const void* x, const void* w_ph, const float* bias4, void* y, int N, int H, int W, int Cin, int Cout,
                     int dtype, void* stream);

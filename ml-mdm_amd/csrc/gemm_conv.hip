@@ -1954,6 +1954,32 @@ __global__ __launch_bounds__(256) void upconv_pack_kernel(const float* __restric
         }
 }
 
+// one thread per (co, ci): w (Cout, Cin, 3, 3) fp32 -> the input-gradient pack of the stride-2 convolution,
+// w_sel [(ph, pw, ci)][Cout / 64][tap j = 2 dh + dw][64] bf16: dx[2b + p] += dy[b + d] * W[k(p, d)] per axis with
+// k(0, 0) = 1, k(1, 0) = 2, k(1, 1) = 0 and no tap for (p, d) = (0, 1) (zero block)
+__global__ __launch_bounds__(256) void s2dgrad_pack_kernel(const float* __restrict__ w, bf16* __restrict__ w_sel, int Cout,
+                                                           int Cin) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Cout * Cin) return;
+  const int co = idx / Cin, ci = idx - co * Cin;
+  float t[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) t[k] = w[(size_t)idx * 9 + k];
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+      for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+          const int kh = ph == 0 ? (dh == 0 ? 1 : -1) : (dh == 0 ? 2 : 0);
+          const int kw = pw == 0 ? (dw == 0 ? 1 : -1) : (dw == 0 ? 2 : 0);
+          const float v = (kh >= 0 && kw >= 0) ? t[kh * 3 + kw] : 0.f;
+          w_sel[(((size_t)((ph * 2 + pw) * Cin + ci) * (Cout >> 6) + (co >> 6)) * 4 + dh * 2 + dw) * 64 + (co & 63)] = (bf16)v;
+        }
+}
+
 // dW (Cout, Cin, 3, 3) (+)= the fold of dwb (4 Cout, Cin, 3, 3): the gradient of phase weight (ph, a) x (pw, b) -- stored at
 // low-resolution tap (ph + a, pw + b) of row (phase, co) -- flows to every 3x3 tap summed into it.  Only the 16 computed
 // (phase, tap) blocks are read.  One thread per (co, ci).
@@ -2213,6 +2239,13 @@ extern "C" int mdm_upconv_pack(const float* w_oihw, void* w_ph, void* w_t, int C
   MDM_CHECK_ARG(w_oihw && w_ph && w_t && Cout % 64 == 0 && Cin % 64 == 0);
   hipLaunchKernelGGL(upconv_pack_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      w_oihw, (bf16*)w_ph, (bf16*)w_t, Cout, Cin);
+  MDM_LAUNCH_STATUS();
+}
+// w (Cout, Cin, 3, 3) fp32 -> the bf16 pack mdm_conv_s2_dgrad reads
+extern "C" int mdm_s2dgrad_pack(const float* w_oihw, void* w_sel, int Cout, int Cin, void* stream) {
+  MDM_CHECK_ARG(w_oihw && w_sel && Cout % 64 == 0 && Cin > 0);
+  hipLaunchKernelGGL(s2dgrad_pack_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     w_oihw, (bf16*)w_sel, Cout, Cin);
   MDM_LAUNCH_STATUS();
 }
 // dW (Cout, Cin, 3, 3) (+)= fold of dwb (4 Cout, Cin, 3, 3) (see mdm_conv_wgrad_blocked); dbias (Cout) (+)= the four

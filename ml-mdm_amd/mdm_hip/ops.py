@@ -395,13 +395,13 @@ def packed_s2_dgrad_weight(weight: torch.Tensor):
     if "s2dgrad" in ent and ent["s2dgrad"][0] == ver:
         return ent["s2dgrad"][1]
     cout, cin = weight.shape[0], weight.shape[1]
-    w = weight.detach().float()
-    sel = w.new_zeros(2, 2, cin, 2, 2, cout)            # [ph, pw, ci, dh, dw, co]
-    pairs = ((0, 0, 1), (1, 0, 2), (1, 1, 0))           # (phase, offset, kernel tap)
-    for ph, dh, kh in pairs:
-        for pw, dw, kw in pairs:
-            sel[ph, pw, :, dh, dw, :] = w[:, :, kh, kw].t()
-    packed = sel.reshape(4 * cin, 4, cout // 64, 64).permute(0, 2, 1, 3).contiguous().to(torch.bfloat16)
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    old = ent.get("s2dgrad")
+    packed = old[1] if old is not None and old[1].shape == (4 * cin, cout // 64, 4, 64) else \
+        torch.empty((4 * cin, cout // 64, 4, 64), dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.lib().mdm_s2dgrad_pack(_p(w), _p(packed), cout, cin, _stream()), "mdm_s2dgrad_pack")
     ent["s2dgrad"] = (ver, packed)
     return packed
 
