@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: denoise train steps/s of the cc12m_64x64 U-Net (bf16, batch 64 per GPU).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -194,8 +194,8 @@ def timed_steps(step, sample, warmup, steps, sync):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="unet64", choices=["unet64", "nested256", "mini"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 / 16)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -315,7 +315,7 @@ def main():
         nstep, nopt = make_step(npipe, True, world, bucket_mb=args.bucket_mb, wire=wire)
         nsample = synthetic_batch(16, nside, device, seed=99 + rank)
         nsteps = max(3, min(args.steps, 10))
-        ndt = timed_steps(nstep, nsample, 2, nsteps, sync)
+        ndt = timed_steps(nstep, nsample, 4, nsteps, sync)   # 4 warm-up steps: the allocator re-grows after empty_cache()
         if world > 1:
             tt = torch.tensor([ndt], device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
