@@ -49,13 +49,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     if (tr < rows_par) {
       Chunk<T> k;
       k.load(xn + (size_t)(c0 + tc) * EPV);
-      for (int p = p_begin + tr; p < p_end; p += rows_par) {
-        Chunk<T> ch;
-        ch.load(xn + (size_t)p * C + (size_t)(c0 + tc) * EPV);
+      // four pixel rows per trip: the four loads are in flight together (a slab is a few thousand rows per thread
+      // column at batch 1-16, and one 16-byte load per round trip left the memory system idle); same summation order
+      for (int p = p_begin + tr; p < p_end; p += 4 * rows_par) {
+        uint4 raw[4];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-          const float d = ch.v[e] - k.v[e];
-          s1[e] += d; s2[e] += d * d;
+        for (int u = 0; u < 4; ++u) {
+          const int pu = p + u * rows_par;
+          raw[u] = pu < p_end ? *reinterpret_cast<const uint4*>(xn + (size_t)pu * C + (size_t)(c0 + tc) * EPV) : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (p + u * rows_par < p_end) {
+            Chunk<T> ch;
+            ch.load(reinterpret_cast<const T*>(&raw[u]));
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+              const float d = ch.v[e] - k.v[e];
+              s1[e] += d; s2[e] += d * d;
+            }
+          }
         }
       }
     }
@@ -84,6 +97,41 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 // stores stats / coef for the backward pass.
 constexpr int GN_MAXCB = 128;   // channels per block slice (upper bound; host picks CB <= this)
 
+// (sum over slabs of part[n][slab][cb0 + c][0..1]) for the CB channels of a block, by all 256 threads: thread t sums the
+// slabs t / CB, t / CB + 256 / CB, ... of channel t % CB four loads at a time, the 256 / CB partial sums are added in a
+// fixed order.  One thread per channel walking the slabs serially (one dependent L2 round trip each) capped the slab
+// count at 32 per sample, which left the partial stage with 128 blocks at batch 4.
+__device__ __forceinline__ void gn_slab_sums(const float* __restrict__ part, int n, int slabs, int C, int cb0, int CB,
+                                             float* __restrict__ red /* [256][2] */, float* __restrict__ o1,
+                                             float* __restrict__ o2) {
+  const int tid = threadIdx.x;
+  const int nsub = 256 / CB;                      // CB <= 128 -> nsub >= 2
+  const int c = tid % CB, sub = tid / CB;
+  float a = 0.f, b = 0.f;
+  if (sub < nsub) {
+    const float* pp = part + ((size_t)n * slabs * C + cb0 + c) * 2;
+    int s_ = sub;
+    for (; s_ + 3 * nsub < slabs; s_ += 4 * nsub) {
+      const float2 v0 = *reinterpret_cast<const float2*>(pp + (size_t)s_ * C * 2);
+      const float2 v1 = *reinterpret_cast<const float2*>(pp + (size_t)(s_ + nsub) * C * 2);
+      const float2 v2 = *reinterpret_cast<const float2*>(pp + (size_t)(s_ + 2 * nsub) * C * 2);
+      const float2 v3 = *reinterpret_cast<const float2*>(pp + (size_t)(s_ + 3 * nsub) * C * 2);
+      a += v0.x; b += v0.y; a += v1.x; b += v1.y; a += v2.x; b += v2.y; a += v3.x; b += v3.y;
+    }
+    for (; s_ < slabs; s_ += nsub) {
+      const float2 v = *reinterpret_cast<const float2*>(pp + (size_t)s_ * C * 2);
+      a += v.x; b += v.y;
+    }
+  }
+  red[tid * 2] = a; red[tid * 2 + 1] = b;
+  __syncthreads();
+  if (tid < CB) {
+    float ta = 0.f, tb = 0.f;
+    for (int j = 0; j < nsub; ++j) { ta += red[(j * CB + tid) * 2]; tb += red[(j * CB + tid) * 2 + 1]; }
+    o1[tid] = ta; o2[tid] = tb;
+  }
+}
+
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -96,15 +144,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   const int n = blockIdx.z, cb0 = blockIdx.y * CB, tid = threadIdx.x;
   const int cpg = C / G, gpb = CB / cpg;
   const T* xn = x + (size_t)n * HW * C;
-  if (tid < CB) {
-    const int c = cb0 + tid;
-    float a = 0.f, b = 0.f;
-    for (int s_ = 0; s_ < slabs; ++s_) {
-      const float* pp = part + (((size_t)n * slabs + s_) * C + c) * 2;
-      a += pp[0]; b += pp[1];
-    }
-    sh_s1[tid] = a; sh_s2[tid] = b; sh_k[tid] = to_f32(xn[c]);
-  }
+  __shared__ float sh_red[512];
+  gn_slab_sums(part, n, slabs, C, cb0, CB, sh_red, sh_s1, sh_s2);
+  if (tid < CB) sh_k[tid] = to_f32(xn[cb0 + tid]);
   __syncthreads();
   const float cnt = (float)HW;
   if (tid < gpb) {
@@ -149,15 +191,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   for (int e = 0; e < EPV; ++e) { a[e] = sh_a[cl * EPV + e]; b[e] = sh_b[cl * EPV + e]; }
   const int px0 = blockIdx.x * pix_per_block, px1 = min(HW, px0 + pix_per_block);
   const size_t base = (size_t)n * HW * C + cb0 + cl * EPV;
-  for (int p = px0 + rl; p < px1; p += rows_par) {
-    Chunk<T> ch;
-    ch.load(x + base + (size_t)p * C);
+  for (int p = px0 + rl; p < px1; p += 4 * rows_par) {
+    uint4 raw[4];
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-      const float z = a[e] * ch.v[e] + b[e];
-      ch.v[e] = ACT ? silu_f(z) : z;
+    for (int u = 0; u < 4; ++u) {
+      const int pu = p + u * rows_par;
+      if (pu < px1) raw[u] = *reinterpret_cast<const uint4*>(x + base + (size_t)pu * C);
     }
-    ch.store(y + base + (size_t)p * C);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pu = p + u * rows_par;
+      if (pu < px1) {
+        Chunk<T> ch;
+        ch.load(reinterpret_cast<const T*>(&raw[u]));
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const float z = a[e] * ch.v[e] + b[e];
+          ch.v[e] = ACT ? silu_f(z) : z;
+        }
+        ch.store(y + base + (size_t)pu * C);
+      }
+    }
   }
 }
 
@@ -185,16 +239,30 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict
       float ab[2 * EPV];
 #pragma unroll
       for (int e = 0; e < 2 * EPV; ++e) ab[e] = cf[e];
-      for (int p = p_begin + tr; p < p_end; p += rows_par) {
-        const size_t off = nbase + (size_t)p * C + (size_t)(c0 + tc) * EPV;
-        Chunk<T> cx, cd;
-        cx.load(x + off);
-        cd.load(dy + off);
+      for (int p = p_begin + tr; p < p_end; p += 2 * rows_par) {   // two rows (four loads) in flight, same summation order
+        uint4 rx[2], rd[2];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-          float dz = cd.v[e];
-          if (ACT) dz *= dsilu_f(ab[2 * e] * cx.v[e] + ab[2 * e + 1]);
-          a1[e] += dz; a2[e] += dz * cx.v[e];
+        for (int u = 0; u < 2; ++u) {
+          const int pu = p + u * rows_par;
+          if (pu < p_end) {
+            const size_t off = nbase + (size_t)pu * C + (size_t)(c0 + tc) * EPV;
+            rx[u] = *reinterpret_cast<const uint4*>(x + off);
+            rd[u] = *reinterpret_cast<const uint4*>(dy + off);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (p + u * rows_par < p_end) {
+            Chunk<T> cx, cd;
+            cx.load(reinterpret_cast<const T*>(&rx[u]));
+            cd.load(reinterpret_cast<const T*>(&rd[u]));
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+              float dz = cd.v[e];
+              if (ACT) dz *= dsilu_f(ab[2 * e] * cx.v[e] + ab[2 * e + 1]);
+              a1[e] += dz; a2[e] += dz * cx.v[e];
+            }
+          }
         }
       }
     }
@@ -235,13 +303,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   __shared__ float sh_fgA1[GN_MAXCB], sh_fgXh[GN_MAXCB], sh_a[GN_MAXCB], sh_b[GN_MAXCB], sh_q[GN_MAXCB], sh_r[GN_MAXCB];
   const int n = blockIdx.z, cb0 = blockIdx.y * CB, tid = threadIdx.x;
   const int cpg = C / G, gpb = CB / cpg;
+  __shared__ float sh_red[512], sh_A1[GN_MAXCB], sh_A2[GN_MAXCB];
+  gn_slab_sums(part, n, slabs, C, cb0, CB, sh_red, sh_A1, sh_A2);
   if (tid < CB) {
     const int c = cb0 + tid;
-    float A1 = 0.f, A2 = 0.f;
-    for (int s_ = 0; s_ < slabs; ++s_) {
-      const float* pp = part + (((size_t)n * slabs + s_) * C + c) * 2;
-      A1 += pp[0]; A2 += pp[1];
-    }
+    const float A1 = sh_A1[tid], A2 = sh_A2[tid];   // written by this same thread
     const int g = c / cpg;
     const float mu = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
     const float Xh = rstd * (A2 - mu * A1);
@@ -756,14 +822,15 @@ __global__ __launch_bounds__(256) void ln_multi_param_kernel(LnGroup g, const T*
 
 using namespace mdm;
 
-// pixel slabs of the partial-sum stage: about 1024 blocks in total, but never more than 32 per sample -- every block of
-// the apply stage adds up the slabs of its channels serially (one dependent L2 load each: 256 slabs at batch 4 made a
-// 64 x 64 norm take 71 us, 8x its batch-64 cost per byte)
+// pixel slabs of the partial-sum stage: about 1024 blocks in total, at least 64 pixels each, at most 256 per sample
+// (round 2 capped them at 32 because every apply block walked the slabs of a channel serially -- 256 slabs at batch 4 made
+// a 64 x 64 norm take 71 us; with gn_slab_sums the walk is 256 / CB-way parallel and four loads deep, and the cap that
+// left a 1024 x 1024 x 32 norm at batch 4 with 128 partial blocks (1.5 TB/s) is gone)
 static inline int gn_slabs(int N, int HW) {
   int s = (1024 + N - 1) / N;
-  const int max_s = (HW + 15) / 16;
+  const int max_s = (HW + 63) / 64;
   if (s > max_s) s = max_s;
-  if (s > 32) s = 32;
+  if (s > 256) s = 256;   // the apply blocks add the slabs with all their threads (gn_slab_sums); 32 before
   if (s < 1) s = 1;
   return s;
 }
