@@ -2163,6 +2163,178 @@ static int conv_tile_code(int M, int Cout, int dtype) {
 
 extern "C" int mdm_conv_fwd_tile(int M, int Cout, int dtype) { return conv_tile_code(M, Cout, dtype); }
 
+// ---- direct 3x3 convolution for the narrow outer levels of the nested models (32 / 64 channels at 256^2 ... 1024^2) ----
+// There the implicit GEMM is the wrong shape: N = 32 fills a quarter of an MFMA-friendly tile, and every tap re-reads its
+// shifted copy of the input through L2 -- 280 us for a 1024^2 x 32 -> 32 layer at batch 4 whose HBM bound (read x once,
+// write y once) is 117 us.  This kernel is built around that bound instead:
+//   * a block owns a TH x TW pixel tile and stages the (TH + 2) x (TW + 2) halo of x in LDS ONCE; the nine taps are nine
+//     shifted views of it (zeros outside the image are written during staging);
+//   * the operands are swapped: A = the weights (16 output channels x 32 reduction elements per MFMA, read ONCE per block
+//     into registers -- the whole filter of the wave's output channels: 72-144 VGPRs -- and kept over a persistent tile loop),
+//     B = 16 pixels of the staged tile; D[cout][pixel] then leaves every lane with 4 consecutive output channels of one
+//     pixel, which go to HBM as 8-byte stores without a trip through LDS;
+//   * w is the forward pack [Cout][tap][Cin] (for the input gradient: the dgrad pack with the roles of the channel counts
+//     swapped), bias / residual as in the GEMM epilogue.
+struct DirectArgs {
+  const bf16* x; const bf16* w; const float* bias; const bf16* res; bf16* y;
+  int N, H, W, tiles_x, tiles_y, tiles;
+};
+
+template <int CIN, int COUT, int TH, int TW, int WSPLIT>
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(DirectArgs p) {
+  constexpr int PITCH = CIN * 2 + (CIN == 64 ? 16 : 0);        // bytes per staged pixel (+16: 128-byte rows would 2-way conflict)
+  constexpr int TWH = TW + 2, THH = TH + 2;
+  constexpr int CHUNKS = CIN / 8;                              // 16-byte chunks per pixel
+  constexpr int MB = COUT / WSPLIT / 16;                       // 16-channel output blocks per wave
+  constexpr int KPT = CIN / 32;                                // MFMA reduction steps per tap
+  constexpr int KS = 9 * KPT;
+  constexpr int NB = TW / 16;                                  // 16-pixel blocks per tile row
+  constexpr int RSETS = 4 / WSPLIT;                            // waves sharing the rows of a tile
+  static_assert(TH % RSETS == 0, "rows per wave");
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int cout0 = (wid / RSETS) * (COUT / WSPLIT);
+  const int rset = wid % RSETS;
+
+  // the wave's filter, MFMA A-fragment order: lane (l15, quad) holds w[cout0 + mb * 16 + l15][ks * 32 + quad * 8 .. + 8]
+  Frag<bf16> wf[MB][KS];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wf[mb][ks].v = *reinterpret_cast<const bf16x8*>(p.w + (size_t)(cout0 + mb * 16 + l15) * (9 * CIN) + ks * 32 + quad * 8);
+  float bv[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[mb][i] = p.bias ? p.bias[cout0 + mb * 16 + quad * 4 + i] : 0.f;
+
+  // The halo of a tile travels HBM -> registers -> LDS; the loads of tile t + 1 are issued before the MFMAs of tile t and
+  // land while it computes and stores (one memory round trip per tile, hidden, instead of three exposed ones).
+  constexpr int TOTAL = THH * TWH * CHUNKS;
+  constexpr int NLD = (TOTAL + 255) / 256;
+  uint4 pre[NLD];
+  auto issue = [&](int tile) {
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
+    const int gx0 = tx * TW - 1, gy0 = ty * TH - 1;
+    const bf16* xn = p.x + (size_t)n * p.H * p.W * CIN;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int c = tid + u * 256;      // consecutive threads: consecutive 16-byte chunks of a staged row (contiguous in HBM)
+      pre[u] = uint4{0u, 0u, 0u, 0u};
+      if (c < TOTAL) {
+        const int r = c / (TWH * CHUNKS), rem = c - r * (TWH * CHUNKS);
+        const int px = rem / CHUNKS, ch = rem - px * CHUNKS;
+        const int gy = gy0 + r, gx = gx0 + px;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+          pre[u] = *reinterpret_cast<const uint4*>(xn + ((size_t)gy * p.W + gx) * CIN + ch * 8);
+      }
+    }
+  };
+  if ((int)blockIdx.x < p.tiles) issue(blockIdx.x);
+  for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int c = tid + u * 256;
+      if (c < TOTAL) {
+        const int r = c / (TWH * CHUNKS), rem = c - r * (TWH * CHUNKS);
+        const int px = rem / CHUNKS, ch = rem - px * CHUNKS;
+        *reinterpret_cast<uint4*>(dsm + (r * TWH + px) * PITCH + ch * 16) = pre[u];
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < p.tiles) issue(tile + gridDim.x);
+    auto do_row = [&](int r) {
+      f32x4 acc[NB][MB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int tap = ks / KPT, half = ks % KPT;
+        const int dy = tap / 3, dx = tap % 3;
+        const char* row = dsm + ((r + dy) * TWH + dx + l15) * PITCH + half * 64 + quad * 16;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          Frag<bf16> xb;
+          xb.v = *reinterpret_cast<const bf16x8*>(row + nb * 16 * PITCH);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) mma16(acc[nb][mb], wf[mb][ks], xb);
+        }
+      }
+      // The compiler (ROCm 7.2) reads the accumulators of the LAST MFMA back two instructions after issuing it when the
+      // read sits behind a branch (the residual test): no wait states for the XDL write -> VALU read hazard, and the
+      // first-read components came back stale in the <64, 64, .., 4> instantiation (found by the parity test: channels
+      // 4 q + 2, 4 q + 3 of every second pixel block wrong).  Fence the k-loop from the epilogue and pay the wait states here.
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // acc[nb][mb][i] = y[pixel nb * 16 + l15][cout0 + mb * 16 + quad * 4 + i]
+      const int gy = ty * TH + r;
+      const size_t rowbase = ((size_t)n * p.H + gy) * p.W + tx * TW;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const size_t off = (rowbase + nb * 16 + l15) * COUT + cout0 + mb * 16 + quad * 4;
+          float o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = acc[nb][mb][i] + bv[mb][i];
+          if (p.res) {
+            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.res + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += (float)rv[i];
+          }
+          bf16x4 ov;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ov[i] = (bf16)o[i];
+          *reinterpret_cast<bf16x4*>(p.y + off) = ov;
+        }
+    };
+#pragma unroll 1
+    for (int r = rset; r < TH; r += RSETS) do_row(r);
+    __syncthreads();   // the next tile's staging overwrites what the slower waves may still read
+  }
+}
+
+template <int CIN, int COUT, int TH, int TW, int WSPLIT>
+static int launch_conv_direct(const ConvArgs& a, hipStream_t st) {
+  constexpr int pitch = CIN * 2 + (CIN == 64 ? 16 : 0);
+  constexpr int smem = (TH + 2) * (TW + 2) * pitch;
+  auto kern = conv3x3_direct_kernel<CIN, COUT, TH, TW, WSPLIT>;
+  ensure_dynamic_lds(kern, smem);
+  DirectArgs d;
+  d.x = (const bf16*)a.x; d.w = (const bf16*)a.w; d.bias = a.bias; d.res = (const bf16*)a.res; d.y = (bf16*)a.y;
+  d.N = a.N; d.H = a.H; d.W = a.W; d.tiles_x = a.W / TW; d.tiles_y = a.H / TH; d.tiles = d.tiles_x * d.tiles_y * a.N;
+  const int resident = device_cus() * (160 * 1024 / smem > 2 ? 2 : 1) * 2;   // two waves of blocks per resident slot
+  hipLaunchKernelGGL(kern, dim3(d.tiles < resident ? d.tiles : resident), dim3(256), smem, st, d);
+  MDM_NOTE_KERNEL("conv3x3_direct_kernel<%d, %d, %d, %d, %d>", CIN, COUT, TH, TW, WSPLIT);
+  MDM_LAUNCH_STATUS();
+}
+
+// usable for this problem?  (bf16, 3x3 stride 1, plain epilogue, 32 / 64 channels both sides, tile-aligned image)
+static bool conv_direct_ok(const ConvArgs& a, int ksize, int transposed, int dtype) {
+  static const int off = getenv("MDM_HIP_CONV_DIRECT") ? atoi(getenv("MDM_HIP_CONV_DIRECT")) == 0 : 0;
+  if (off || dtype != DT_BF16 || ksize != 3 || transposed || a.stride != 1 || a.act != 0 || a.aux || a.ypre) return false;
+  if (!(a.Cin == 32 || a.Cin == 64) || !(a.Cout == 32 || a.Cout == 64)) return false;
+  if (a.kblk != 0 && !(a.kblk == 64 && a.Cin == 64)) return false;      // [Cout][tap][Cin] either way
+  if (a.Ho != a.H || a.Wo != a.W || a.H % 8 != 0 || a.W % 64 != 0) return false;
+  return (long)a.N * a.H * a.W >= 65536 && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.w & 15) == 0;
+}
+
+// WSPLIT = groups of output channels among the 4 waves (each wave keeps the filter of 16-32 output channels in registers and
+// walks 8 / (4 / WSPLIT) rows of the tile): chosen so that filter + accumulators + the prefetched halo stay under 256 VGPRs
+// (2 blocks per CU)
+static int launch_conv_direct_any(const ConvArgs& a, hipStream_t st) {
+  if (a.Cin == 32 && a.Cout == 32) return launch_conv_direct<32, 32, 8, 64, 1>(a, st);
+  if (a.Cin == 32 && a.Cout == 64) return launch_conv_direct<32, 64, 8, 64, 4>(a, st);
+  if (a.Cin == 64 && a.Cout == 32) return launch_conv_direct<64, 32, 8, 32, 2>(a, st);
+  return launch_conv_direct<64, 64, 8, 32, 4>(a, st);
+}
+
 template <typename T, int MODE>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE>(a, st);
@@ -2215,6 +2387,7 @@ extern "C" int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float*
   a.kblk = kblock;
   a.part = nullptr; a.ksplit = 1; a.kt_per = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (conv_direct_ok(a, ksize, transposed, dtype)) return launch_conv_direct_any(a, st);
   if (ws && dtype == DT_BF16 && !transposed && stride == 1) {
     const int sp = conv_ksplit(a.M, Cout, a.K, dtype);
     if (sp > 1 && ws_bytes >= (size_t)sp * a.M * Cout * sizeof(float)) {

@@ -72,6 +72,12 @@ def nchw(t_nhwc):
         # 1024 tiles of 128x128 on 512 resident blocks: the persistent kernel's second output tile per block
         (8, 128, 128, 64, 128, 1, 1),   # single k-tile (K = 64)
         (8, 128, 128, 64, 128, 3, 1),
+        # 32 / 64 channels on both sides, >= 65536 pixels, W % 64 == 0, H % 8 == 0 (bf16): the direct halo-tile kernel
+        # (conv3x3_direct_kernel) forward and -- with the channel counts swapped -- input gradient
+        (4, 128, 128, 32, 32, 3, 1),
+        (2, 136, 256, 32, 64, 3, 1),    # 17 tile rows, two output-channel halves per block
+        (4, 128, 128, 64, 32, 3, 1),    # 32-pixel-wide tiles, padded LDS rows
+        (1, 256, 256, 64, 64, 3, 1),
     ],
 )
 def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
