@@ -548,3 +548,5 @@ def test_long_horizon_sampling_matches_reference(name, tmp_path):
         errs[mode] = O.rel_l2(out.float()[..., ::st, ::st], gold["out"]["sub"])
     pipe.sampler.device_rng = None
     print("[long sampling %s: %d steps, B=%d] rel-L2 vs the reference: fp32 %.3e, bf16 autocast %.3e" % (name, steps, B, errs["fp32"], errs["bf16"]))
+    # measured (round 3): fp32 1.2e-6 / 6.7e-7 / 5.5e-7; bf16 autocast 8.2e-3 (nested-1024, 25 steps), 4.4e-3 (UNet-64, 50 / 100 steps)
+    assert errs["bf16"] < 2.5e-2
