@@ -2212,38 +2212,43 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(DirectArgs p) {
 
   // The halo of a tile travels HBM -> registers -> LDS; the loads of tile t + 1 are issued before the MFMAs of tile t and
   // land while it computes and stores (one memory round trip per tile, hidden, instead of three exposed ones).
-  constexpr int TOTAL = THH * TWH * CHUNKS;
-  constexpr int NLD = (TOTAL + 255) / 256;
+  // Staging map: thread `tid` owns the 16-byte chunk column `tid` of every staged row (a staged row is TWH * CHUNKS = 264 /
+  // 272 chunks, contiguous in HBM), the few columns past 256 are spread over the first threads -- so the addresses are
+  // affine in the row (one pointer + a row stride), the row test is scalar, and nothing per load has to be kept in VGPRs.
+  constexpr int COLS = TWH * CHUNKS, REM = COLS - 256;
+  static_assert(REM > 0 && REM * THH <= 256, "staging map");
+  constexpr int NLD = THH + 1;
   uint4 pre[NLD];
+  const int mpx = tid / CHUNKS, mch = tid % CHUNKS;                                   // main column
+  const int er = tid / REM, ecol = 256 + tid % REM, epx = ecol / CHUNKS, ech = ecol % CHUNKS;   // extra chunk (tid < REM * THH)
+  const bool has_extra = tid < REM * THH;
   auto issue = [&](int tile) {
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
     const int gx0 = tx * TW - 1, gy0 = ty * TH - 1;
     const bf16* xn = p.x + (size_t)n * p.H * p.W * CIN;
+    const int gx = gx0 + mpx;
+    const bool okx = gx >= 0 && gx < p.W;
+    const bf16* col = xn + ((ptrdiff_t)gy0 * p.W + gx) * CIN + mch * 8;
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int c = tid + u * 256;      // consecutive threads: consecutive 16-byte chunks of a staged row (contiguous in HBM)
-      pre[u] = uint4{0u, 0u, 0u, 0u};
-      if (c < TOTAL) {
-        const int r = c / (TWH * CHUNKS), rem = c - r * (TWH * CHUNKS);
-        const int px = rem / CHUNKS, ch = rem - px * CHUNKS;
-        const int gy = gy0 + r, gx = gx0 + px;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-          pre[u] = *reinterpret_cast<const uint4*>(xn + ((size_t)gy * p.W + gx) * CIN + ch * 8);
-      }
+    for (int r = 0; r < THH; ++r) {
+      const int gy = gy0 + r;
+      pre[r] = uint4{0u, 0u, 0u, 0u};
+      if (okx && gy >= 0 && gy < p.H) pre[r] = *reinterpret_cast<const uint4*>(col + (ptrdiff_t)r * p.W * CIN);
+    }
+    pre[THH] = uint4{0u, 0u, 0u, 0u};
+    if (has_extra) {
+      const int gy = gy0 + er, gxe = gx0 + epx;
+      if (gy >= 0 && gy < p.H && gxe >= 0 && gxe < p.W)
+        pre[THH] = *reinterpret_cast<const uint4*>(xn + ((size_t)gy * p.W + gxe) * CIN + ech * 8);
     }
   };
   if ((int)blockIdx.x < p.tiles) issue(blockIdx.x);
   for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int c = tid + u * 256;
-      if (c < TOTAL) {
-        const int r = c / (TWH * CHUNKS), rem = c - r * (TWH * CHUNKS);
-        const int px = rem / CHUNKS, ch = rem - px * CHUNKS;
-        *reinterpret_cast<uint4*>(dsm + (r * TWH + px) * PITCH + ch * 16) = pre[u];
-      }
-    }
+    for (int r = 0; r < THH; ++r)
+      *reinterpret_cast<uint4*>(dsm + (r * TWH + mpx) * PITCH + mch * 16) = pre[r];
+    if (has_extra) *reinterpret_cast<uint4*>(dsm + (er * TWH + epx) * PITCH + ech * 16) = pre[THH];
     __syncthreads();
     if (tile + (int)gridDim.x < p.tiles) issue(tile + gridDim.x);
     auto do_row = [&](int r) {
@@ -2309,7 +2314,8 @@ static int launch_conv_direct(const ConvArgs& a, hipStream_t st) {
   DirectArgs d;
   d.x = (const bf16*)a.x; d.w = (const bf16*)a.w; d.bias = a.bias; d.res = (const bf16*)a.res; d.y = (bf16*)a.y;
   d.N = a.N; d.H = a.H; d.W = a.W; d.tiles_x = a.W / TW; d.tiles_y = a.H / TH; d.tiles = d.tiles_x * d.tiles_y * a.N;
-  const int resident = device_cus() * (160 * 1024 / smem > 2 ? 2 : 1) * 2;   // two waves of blocks per resident slot
+  const int per_cu = 160 * 1024 / smem >= 3 ? 3 : (160 * 1024 / smem >= 2 ? 2 : 1);   // 3 waves / SIMD by registers
+  const int resident = device_cus() * per_cu * 2;                                       // two rounds of blocks: the second balances the tail
   hipLaunchKernelGGL(kern, dim3(d.tiles < resident ? d.tiles : resident), dim3(256), smem, st, d);
   MDM_NOTE_KERNEL("conv3x3_direct_kernel<%d, %d, %d, %d, %d>", CIN, COUT, TH, TW, WSPLIT);
   MDM_LAUNCH_STATUS();
@@ -2329,7 +2335,7 @@ static bool conv_direct_ok(const ConvArgs& a, int ksize, int transposed, int dty
 // walks 8 / (4 / WSPLIT) rows of the tile): chosen so that filter + accumulators + the prefetched halo stay under 256 VGPRs
 // (2 blocks per CU)
 static int launch_conv_direct_any(const ConvArgs& a, hipStream_t st) {
-  if (a.Cin == 32 && a.Cout == 32) return launch_conv_direct<32, 32, 8, 64, 1>(a, st);
+  if (a.Cin == 32 && a.Cout == 32) return launch_conv_direct<32, 32, 8, 64, 2>(a, st);
   if (a.Cin == 32 && a.Cout == 64) return launch_conv_direct<32, 64, 8, 64, 4>(a, st);
   if (a.Cin == 64 && a.Cout == 32) return launch_conv_direct<64, 32, 8, 32, 2>(a, st);
   return launch_conv_direct<64, 64, 8, 32, 4>(a, st);
