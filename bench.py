@@ -311,21 +311,26 @@ def main():
         ops.set_grad_sink(None)
         pipe = sample = None
         torch.cuda.empty_cache()
-        npipe, nside = build("nested256", device)
-        nstep, nopt = make_step(npipe, True, world, bucket_mb=args.bucket_mb, wire=wire)
-        nsample = synthetic_batch(16, nside, device, seed=99 + rank)
-        nsteps = max(3, min(args.steps, 10))
-        ndt = timed_steps(nstep, nsample, 4, nsteps, sync)   # 4 warm-up steps: the allocator re-grows after empty_cache()
-        if world > 1:
-            tt = torch.tensor([ndt], device=device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ndt = float(tt.item())
-        nflop = 3 * FWD_GFLOP_PER_SAMPLE["nested256"] * 16 / 1e3
-        assert getattr(nopt, "_mdm_fused", False) not in (None, False)
-        nested = {"workload": "cc12m_256x256 NestedUNet (64+256) train step, bf16, per-GPU batch 16", "steps": nsteps,
-                  "ms_per_step": round(ndt / nsteps * 1e3, 3), "steps_per_s_whole_job": round(world * nsteps / ndt, 4),
-                  "step_algorithmic_tflop": round(nflop, 2),
-                  "step_mfma_roofline_frac": round(nflop / (ndt / nsteps) / PEAK_BF16_TFLOPS, 4)}
+        try:
+            npipe, nside = build("nested256", device)
+            nstep, nopt = make_step(npipe, True, world, bucket_mb=args.bucket_mb, wire=wire)
+            nsample = synthetic_batch(16, nside, device, seed=99 + rank)
+            nsteps = max(3, min(args.steps, 10))
+            ndt = timed_steps(nstep, nsample, 4, nsteps, sync)   # 4 warm-up steps: the allocator re-grows after empty_cache()
+            if world > 1:
+                tt = torch.tensor([ndt], device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ndt = float(tt.item())
+            nflop = 3 * FWD_GFLOP_PER_SAMPLE["nested256"] * 16 / 1e3
+            assert getattr(nopt, "_mdm_fused", False) not in (None, False)
+            nested = {"workload": "cc12m_256x256 NestedUNet (64+256) train step, bf16, per-GPU batch 16", "steps": nsteps,
+                      "ms_per_step": round(ndt / nsteps * 1e3, 3), "steps_per_s_whole_job": round(world * nsteps / ndt, 4),
+                      "step_algorithmic_tflop": round(nflop, 2),
+                      "step_mfma_roofline_frac": round(nflop / (ndt / nsteps) / PEAK_BF16_TFLOPS, 4)}
+        except Exception as ex:   # a secondary measurement never takes the headline line down (one process; with several
+            if world > 1:         # ranks a local failure would leave the others in a collective, so it propagates)
+                raise
+            nested = {"error": str(ex)[:200]}
 
     # the same entry point on its PLAIN path: what the CLI's own objects do when nothing is adopted into arenas
     ref_loop = None
