@@ -186,3 +186,25 @@ def test_philox_reference_known_answers():
     assert run((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
     z = P.normals(1 << 18, seed=42)
     assert abs(float(z.mean())) < 1e-2 and abs(float(z.std()) - 1.0) < 1e-2
+
+
+def test_no_mfma_result_is_read_back_early_on_a_branch_edge():
+    """tools/mfma_hazard_scan.py over the ISA of the two MFMA-bearing sources: no read of an MFMA's destination registers
+    within 6 wait states on ANY path, taken branch edges included.  ROCm 7.2's hazard recognizer missed exactly that in
+    conv3x3_direct_kernel<64, 64, 8, 32, 4> (stale accumulators, caught by the GPU parity test; the kernel now fences its
+    k-loop from its epilogue) -- this keeps a recompile from reintroducing it silently.  Cross-compiles, no GPU needed."""
+    import importlib.util
+    import shutil
+
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    spec = importlib.util.spec_from_file_location(
+        "mfma_hazard_scan", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "mfma_hazard_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = __import__("sys").argv
+    __import__("sys").argv = ["mfma_hazard_scan.py"]
+    try:
+        assert mod.main() == 0
+    finally:
+        __import__("sys").argv = old

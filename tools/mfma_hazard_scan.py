@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Static check of the compiled kernels for the hazard found in round 3: an MFMA result read back (v_accvgpr_read, VALU,
+LDS / global store) with too few wait states when the read sits on the TAKEN edge of a branch -- ROCm 7.2's hazard
+recognizer covered the fall-through path only (conv3x3_direct_kernel<64, 64, 8, 32, 4>).
+Walks every path of up to 10 wait states after each v_mfma (following branches) and reports reads of its destination
+registers that come earlier than `MIN_WS` (the compiler itself leaves 11 in straight-line code).  CPU-only:
+   python tools/mfma_hazard_scan.py            # compiles csrc/gemm_conv.hip and attention.hip to ISA, exits 1 on a finding"""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MIN_WS = 6
+
+
+def regs(tok):
+    out = set()
+    for m in re.finditer(r"\b([av])\[(\d+):(\d+)\]", tok):
+        out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+    for m in re.finditer(r"\b([av])(\d+)\b", tok):
+        out.add((m.group(1), int(m.group(2))))
+    return out
+
+
+def analyze(path):
+    txt = open(path).read()
+    findings = []
+    for km in re.finditer(r"^(\S+):\s*; @\1\n", txt, re.M):
+        name, i = km.group(1), km.end()
+        lines = [ln.strip() for ln in txt[i:txt.find(".Lfunc_end", i)].split("\n")]
+        labels = {m.group(1): k for k, ln in enumerate(lines) for m in [re.match(r"^(\.LBB\w+):", ln)] if m}
+        code = [(k, ln) for k, ln in enumerate(lines) if ln and not ln.startswith(";") and not ln.startswith(".")]
+        for n, (_, ln) in enumerate(code):
+            if not ln.startswith("v_mfma"):
+                continue
+            dst = regs(ln.split(None, 1)[1].split(",")[0])
+            stack = [(n + 1, 0)]
+            while stack:
+                pos, ws = stack.pop()
+                while pos < len(code) and ws < 10:
+                    ll = code[pos][1]
+                    op = ll.split()[0]
+                    if op == "s_nop":
+                        ws += int(ll.split()[1]) + 1
+                    elif op.startswith("v_mfma"):
+                        if regs(ll.split(None, 1)[1].split(",")[0]) & dst:
+                            break                      # accumulates into / overwrites it: interlocked by hardware
+                        ws += 4
+                    else:
+                        parts = [p.strip() for p in (ll.split(None, 1)[1] if " " in ll else "").split(",")]
+                        stores = op.startswith(("global_store", "ds_write", "buffer_store", "scratch_store"))
+                        used = set()
+                        for t in (parts if stores else parts[1:]):
+                            used |= regs(t)
+                        if used & dst:
+                            findings.append((name, ws, ln, ll))
+                            break
+                        if op.startswith("s_cbranch") or op == "s_branch":
+                            tgt = ll.split()[-1]
+                            if tgt in labels:
+                                nxt = [nn for nn, (k2, _) in enumerate(code) if k2 > labels[tgt]]
+                                if nxt:
+                                    stack.append((nxt[0], ws + 1))
+                            if op == "s_branch":
+                                break
+                        ws += 1
+                    pos += 1
+    return findings
+
+
+def main():
+    srcs = sys.argv[1:] or ["gemm_conv.hip", "attention.hip"]
+    bad = 0
+    with tempfile.TemporaryDirectory() as td:
+        for s in srcs:
+            src = s if os.path.exists(s) else os.path.join(ROOT, "ml-mdm_amd", "csrc", s)
+            out = os.path.join(td, os.path.basename(src) + ".s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                                   "-I" + os.path.join(ROOT, "ml-mdm_amd", "csrc"), "-S", "--cuda-device-only", src, "-o", out])
+            fs = analyze(out)
+            early = [f for f in fs if f[1] < MIN_WS]
+            print("%s: %d reads within 10 wait states of their MFMA, %d earlier than %d" % (os.path.basename(src), len(fs), len(early), MIN_WS))
+            for (name, ws), cnt in sorted(collections.Counter((f[0], f[1]) for f in early).items()):
+                print("   %d wait states, x%d: %s" % (ws, cnt, name[:100]))
+            bad += len(early)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
