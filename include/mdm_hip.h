@@ -71,6 +71,10 @@ int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, i
  * kblock_fwd, kblock_dgrad, first_block}; first_block = running sum of (Cout/32)*(Cin/32); total_blocks = the final
  * sum.  Needs Cout % 32 == 0 and Cin % 32 == 0 (no channel padding) for every entry. */
 int mdm_pack_weights_multi(const void* table, int n, int total_blocks, int dtype, void* stream);
+/* mdm_conv_fwd picks the kernel: the implicit-GEMM tiles (256x256 / 256x192 / 128x128, by tile count), or -- bf16 3x3
+ * stride 1 with 32 / 64 channels on both sides, plain epilogue, >= 65536 pixels, H % 8 == 0, W % 64 == 0: the narrow outer
+ * levels of the nested models (nested_unet.py:109-128, resolution_channels [32, 32, 64] / [64, 128, ...]) -- a direct
+ * convolution that stages each halo tile once (conv3x3_direct_kernel); same arguments, same rounding points. */
 int mdm_conv_fwd(const void* x, const void* w_packed, const float* bias, const void* res, const void* aux, void* y,
                  void* y_pre, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ksize, int stride,
                  int transposed, int act, int kblock, int dtype, void* stream);
