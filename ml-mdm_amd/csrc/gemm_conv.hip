@@ -25,53 +25,11 @@
 #include <utility>
 
 #include "common.hpp"
+#include "conv_args.hpp"
 
 namespace mdm {
 
-struct ConvArgs {
-  const void* x;      // activation (A source) [N, H, W, Cin]
-  const void* w;      // packed weight [Cout][K]
-  const float* bias;  // [Cout] or null
-  const void* res;    // residual [M, Cout] or null (added last)
-  const void* aux;    // pre-activation for act==2 [M, Cout]
-  void* y;            // output [M, Cout]
-  void* ypre;         // optional pre-GELU output (act==1) or null
-  int N, H, W, Cin;   // geometry of x
-  int Ho, Wo, Cout;   // geometry of y
-  int stride;
-  int M, K;
-  int groups;         // grouped launches only (ConvGroup)
-  int act;            // 0 none, 1 y=gelu(v), 2 y=v*gelu'(aux)
-  int kblk;           // 3x3 k-order: 0 = tap-major (k = tap*Cin + cin); B = channel-block-major,
-                      // k = (cin / B) * 9 * B + tap * B + cin % B with B = the k-tile (64 bf16 / 32 fp32)
-  // split-K launches (conv_gemm_bl_kernel<..., SPLITK>): the reduction is cut into `ksplit` ranges of `kt_per` k-tiles,
-  // range s writes its raw fp32 tile to part[s][M][Cout]; splitk_epilogue_kernel adds them up and applies the epilogue
-  float* part;
-  int ksplit, kt_per;
-  // tap selection (conv_gemm_bl_kernel<..., SEL4>): 4 of the 9 taps per channel block, tap = base + (j & 1) + 3 * (j >> 1)
-  //   sel_mode 0: one base for the whole launch (sel_base; 4 = the stride-2 input gradient)
-  //   sel_mode 1: base by OUTPUT phase, phase = column tile's n0 / sel_cout (sub-pixel form of upsample2x -> conv3x3:
-  //               output columns are (phase, co), phase (ph, pw) reads the low-res taps {ph, ph+1} x {pw, pw+1})
-  //   sel_mode 2: base by INPUT phase: the reduction runs over (phase, channel block, tap) of a 2x2-blocked input with
-  //               sel_cout channels per phase (input gradient of the same op); base = (1 - ph) * 3 + (1 - pw)
-  int sel_mode, sel_base, sel_cout;
-  // pixel-shuffled store (ps_cout > 0): output column (phase, co), row (n, bh, bw) of a ps_H x ps_W grid goes to
-  // y[n, 2 bh + ph, 2 bw + pw, co] of a [N, 2 ps_H, 2 ps_W, ps_cout] tensor (a column tile lies inside one phase)
-  int ps_cout, ps_H, ps_W;
-  // GroupNorm of the OUTPUT fused into the epilogue (gn_y != null; 256x192 tile, bf16): a row tile is the 256 pixels of
-  // one sample and a column tile 8 whole groups of 24 channels, so the tile holds everything the statistics need.
-  // Besides y the launch writes gn_y = act(GroupNorm(y)), the norm's stats [N][G][2] and coef [N][C][2] (what
-  // mdm_gn_fwd would have produced from y: the standalone norm kernel and its read of y disappear).
-  void* gn_y;
-  const float* gn_gamma;
-  const float* gn_beta;
-  float* gn_stats;
-  float* gn_coef;
-  float gn_eps;
-  int gn_act, gn_groups;
-};
 
-enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };
 
 // 4 consecutive elements (8 / 16 bytes, aligned) -> fp32
 __device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
@@ -1874,6 +1832,8 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
 
 }  // namespace mdm
 
+#include "gemm_x.hpp"
+
 using namespace mdm;
 
 // ---------------------------------------------------------------------------
@@ -2341,6 +2301,56 @@ static int launch_conv_direct_any(const ConvArgs& a, hipStream_t st) {
   return launch_conv_direct<64, 64, 8, 32, 4>(a, st);
 }
 
+// ---- conv_gemm_x_kernel (gemm_x.hpp): continuous k-tile stream, the epilogue of tile n under the MFMAs of tile n+1 ----
+static int g_force_x = 0;   // development knob 3 (mdm_dev_set_knob): 0 = rule below, 1 = never, 2 = whenever the kernel can
+static int g_x_order = 1;   // development knob 4: 0 = row-major tile order, 1 = super-tiles (below)
+template <int MODE, int ACT, bool RES>
+static int launch_conv_x(const ConvArgs& a0, hipStream_t st) {
+  auto kern = conv_gemm_x_kernel<MODE, ACT, RES>;
+  ensure_dynamic_lds(kern, XG::LDS);
+  ConvArgs a = a0;
+  const int tiles_m = a.M / XG::BM, tiles_n = a.Cout / XG::BN;
+  const int tiles = tiles_m * tiles_n;
+  // super-tile shape (SA row tiles x SB column tiles, ~32 tiles = what one XCD runs at a time): SB = the divisor of the
+  // column-tile count closest to 8 from below, SA = the divisor of the row-tile count closest to 32 / SB from below
+  int SB = tiles_n, SA = 1;
+  if (g_x_order == 1) {
+    SB = 1;
+    for (int d = 1; d <= 8 && d <= tiles_n; ++d) if (tiles_n % d == 0) SB = d;
+    const int want = 32 / SB > 0 ? 32 / SB : 1;
+    for (int d = 1; d <= want && d <= tiles_m; ++d) if (tiles_m % d == 0) SA = d;
+  }
+  a.sel_base = SB; a.sel_cout = SA;
+  const int resident = device_cus();
+  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(256), XG::LDS, st, a);
+  MDM_NOTE_KERNEL("conv_gemm_x_kernel<%d, %d, %d>", MODE, ACT, (int)RES);
+  MDM_LAUNCH_STATUS();
+}
+// can the kernel express this problem?  (conv_bl_ok<bf16, MODE>(a) is checked by the caller)
+static bool conv_x_can(const ConvArgs& a) {
+  if (a.M % XG::BM != 0 || a.Cout % XG::BN != 0 || a.K % 64 != 0 || a.K < 384) return false;
+  if (a.ps_cout > 0 || a.gn_y || a.part) return false;
+  if (a.act == 2 ? (a.res != nullptr || !a.aux) : (a.act == 1 && a.res != nullptr)) return false;
+  return (size_t)a.M * a.Cout * 2 < 0x7F000000u;
+}
+// ... and is it the better choice?  Its strength is the hidden per-tile tail, its price a 256 x 128 tile (1.5x the
+// operand traffic per FLOP of 256 x 256): worth it when a block works through several tiles and the tail is a large
+// part of a tile's time (short reductions, wide outputs, an activation in the epilogue).
+static bool conv_x_wanted(const ConvArgs& a) {
+  if (g_force_x == 1) return false;
+  if (!conv_x_can(a)) return false;
+  if (g_force_x == 2) return true;
+  const long tiles = (long)(a.M / XG::BM) * (a.Cout / XG::BN);
+  return tiles >= 4L * device_cus();
+}
+template <int MODE>
+static int launch_conv_x_any(const ConvArgs& a, hipStream_t st) {
+  if (a.act == 1) return launch_conv_x<MODE, 1, false>(a, st);
+  if (a.act == 2) return launch_conv_x<MODE, 2, false>(a, st);
+  if (a.res) return launch_conv_x<MODE, 0, true>(a, st);
+  return launch_conv_x<MODE, 0, false>(a, st);
+}
+
 template <typename T, int MODE>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE>(a, st);
@@ -2349,6 +2359,7 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if constexpr (MODE != MODE_3x3_T2) {
       if (conv_bl_ok<T, MODE>(a)) {
+        if (conv_x_wanted(a)) return launch_conv_x_any<MODE>(a, st);
         if (code == 256256) return launch_conv_bl<256, 256, 2, 4, MODE>(a, st);
         if (code == 256192) return launch_conv_bl<256, 192, 2, 4, MODE>(a, st);
         return launch_conv_bl<128, 128, 2, 2, MODE>(a, st);
@@ -2568,8 +2579,10 @@ extern "C" int mdm_linear_grouped(const void* const* x, const void* const* w_pac
 }
 
 extern "C" int mdm_dev_set_knob(int idx, int value) {
-  MDM_CHECK_ARG(idx >= 0 && idx < 4);
+  MDM_CHECK_ARG(idx >= 0 && idx < 5);
   if (idx == 2) g_force_tile = value;
+  if (idx == 3) g_force_x = value;
+  if (idx == 4) { g_x_order = value; return 0; }
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdm::g_knobs), &value, sizeof(int), idx * sizeof(int));
 }
 

@@ -32,7 +32,8 @@ class MdmHipError(RuntimeError):
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source for gfx950 into ml-mdm_amd/mdm_hip/libmdm_hip.so (in-tree)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [HEADER, os.path.join(CSRC, "common.hpp")]
+    hdrs = [os.path.join(CSRC, h) for h in ("common.hpp", "conv_args.hpp", "gemm_x.hpp")]
+    deps = srcs + [HEADER] + hdrs
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
             return LIB_PATH
@@ -44,7 +45,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
-        if (not force) and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in (s, HEADER, deps[-1])):
+        if (not force) and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [s, HEADER] + hdrs):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
         if verbose:
