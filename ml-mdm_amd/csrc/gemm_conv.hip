@@ -2322,26 +2322,31 @@ static int launch_conv_x(const ConvArgs& a0, hipStream_t st) {
   }
   a.sel_base = SB; a.sel_cout = SA;
   const int resident = device_cus();
-  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(256), XG::LDS, st, a);
+  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(XG::THREADS), XG::LDS, st, a);
   MDM_NOTE_KERNEL("conv_gemm_x_kernel<%d, %d, %d>", MODE, ACT, (int)RES);
   MDM_LAUNCH_STATUS();
 }
 // can the kernel express this problem?  (conv_bl_ok<bf16, MODE>(a) is checked by the caller)
 static bool conv_x_can(const ConvArgs& a) {
-  if (a.M % XG::BM != 0 || a.Cout % XG::BN != 0 || a.K % 64 != 0 || a.K < 384) return false;
+  if (a.M % XG::BM != 0 || a.Cout % XG::BN != 0 || a.K % 64 != 0 || a.K < 64 * XG::MIN_KTILES) return false;
   if (a.ps_cout > 0 || a.gn_y || a.part) return false;
-  if (a.act == 2 ? (a.res != nullptr || !a.aux) : (a.act == 1 && a.res != nullptr)) return false;
+  if (a.act == 2 ? (a.res != nullptr || !a.aux) : (a.act == 1 && (a.res != nullptr || !a.ypre))) return false;
   return (size_t)a.M * a.Cout * 2 < 0x7F000000u;
 }
-// ... and is it the better choice?  Its strength is the hidden per-tile tail, its price a 256 x 128 tile (1.5x the
-// operand traffic per FLOP of 256 x 256): worth it when a block works through several tiles and the tail is a large
-// part of a tile's time (short reductions, wide outputs, an activation in the epilogue).
-static bool conv_x_wanted(const ConvArgs& a) {
+// ... and is it the better choice?  Its strength is the hidden per-tile tail, its price a 256 x 128 tile: 1.5x the
+// LDS-DMA bytes per FLOP of 256 x 256, and the k-loop of either kernel ends up bound by what a CU's vector-memory path
+// moves (~50 GB/s per CU measured, profiles/r04_gemm_x8_probe.txt).  Measured per layer shape of the U-Net, variants
+// interleaved: it wins where the tail is a large part of a tile -- 1x1 convolutions (K = 512 ... 768) with wide outputs
+// (768 -> 3072 with either activation +9 ... 15 %, 512 -> 1536 +22 %, 512 -> 2048 x gelu'(aux) +16 %) -- ties at
+// 768 -> 2304, and loses on the 3x3 convolutions (long reductions: the tail is small, the operand traffic is not), on
+// N = 768 (1.5 tiles per CU) and on K = 512 with two outputs (GELU + pre-activation: 128 KB of stores per 8 k-tiles).
+static bool conv_x_wanted(const ConvArgs& a, int ksize) {
   if (g_force_x == 1) return false;
   if (!conv_x_can(a)) return false;
   if (g_force_x == 2) return true;
   const long tiles = (long)(a.M / XG::BM) * (a.Cout / XG::BN);
-  return tiles >= 4L * device_cus();
+  if (ksize != 1 || tiles < 5L * device_cus()) return false;
+  return !(a.act == 1 && a.K < 768);
 }
 template <int MODE>
 static int launch_conv_x_any(const ConvArgs& a, hipStream_t st) {
@@ -2359,7 +2364,7 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if constexpr (MODE != MODE_3x3_T2) {
       if (conv_bl_ok<T, MODE>(a)) {
-        if (conv_x_wanted(a)) return launch_conv_x_any<MODE>(a, st);
+        if (conv_x_wanted(a, MODE == MODE_1x1 ? 1 : 3)) return launch_conv_x_any<MODE>(a, st);
         if (code == 256256) return launch_conv_bl<256, 256, 2, 4, MODE>(a, st);
         if (code == 256192) return launch_conv_bl<256, 192, 2, 4, MODE>(a, st);
         return launch_conv_bl<128, 128, 2, 2, MODE>(a, st);
@@ -2580,8 +2585,8 @@ extern "C" int mdm_linear_grouped(const void* const* x, const void* const* w_pac
 
 extern "C" int mdm_dev_set_knob(int idx, int value) {
   MDM_CHECK_ARG(idx >= 0 && idx < 5);
+  if (idx == 3) { g_force_x = value; return 0; }
   if (idx == 2) g_force_tile = value;
-  if (idx == 3) g_force_x = value;
   if (idx == 4) { g_x_order = value; return 0; }
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdm::g_knobs), &value, sizeof(int), idx * sizeof(int));
 }

@@ -107,6 +107,56 @@ def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
     assert relerr(nchw(rd.grad), res.grad) < tol
 
 
+@pytest.mark.parametrize("act,with_res", [(0, False), (0, True), (1, False), (2, False)])
+@pytest.mark.parametrize(
+    "N,H,W,Cin,Cout,ks",
+    [
+        (3, 16, 16, 512, 384, 1),      # 9 tiles on 9 blocks, the shortest reduction the kernel takes (8 k-tiles)
+        (75, 32, 32, 576, 256, 1),     # 600 tiles: 2-3 per block, 9 k-tiles (the drain ends in the tile's last iteration)
+        (10, 32, 16, 64, 128, 3),      # 3x3: image borders inside the tiles, one column tile
+        (75, 32, 32, 64, 256, 3),      # 3x3, several tiles per block
+    ],
+)
+def test_conv_gemm_x_kernel(act, with_res, N, H, W, Cin, Cout, ks):
+    """conv_gemm_x_kernel (csrc/gemm_x.hpp: continuous k-tile stream, two accumulator sets, the epilogue of tile n under the
+    MFMAs of tile n+1) forced through mdm_conv_fwd (development knob 3 = 2) on problems it accepts (M % 256 == 0,
+    Cout % 128 == 0, K >= 512): every epilogue variant (bias, +residual, GELU + pre-activation, x gelu'(aux)), 1x1 and 3x3,
+    several output tiles per block and fewer tiles than CUs, against the torch fp32 ops it replaces (unet.py:199-217,266-272)."""
+    from mdm_hip import _lib, ops
+
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    x = q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    w = q(torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks), dtype)
+    b = torch.randn(Cout, generator=g)
+    pre = q(F.conv2d(x, w, b, padding=(ks - 1) // 2), dtype)            # the conv output as the bf16 graph has it
+    res = q(torch.randn(pre.shape, generator=g), dtype) if with_res else None
+    aux = q(torch.randn(pre.shape, generator=g), dtype) if act == 2 else None
+    if act == 1:
+        y_ref = F.gelu(pre)
+    elif act == 2:
+        a = aux.clone().requires_grad_()
+        y_ref = pre * torch.autograd.grad(F.gelu(a).sum(), a)[0]
+    else:
+        y_ref = pre + (res if with_res else 0)
+    xd = nhwc(x, dtype)
+    wf, wd, bp, cin_p, cout_p, kbf, kbd = ops.packed_weight(w.to(dev()), b.to(dev()), dtype)
+    y = torch.full((N, H, W, Cout), float("nan"), device=dev(), dtype=dtype)
+    ypre = torch.full_like(y, float("nan")) if act == 1 else None
+    L = _lib.lib()
+    L.mdm_dev_set_knob(3, 2)
+    try:
+        ops._conv_launch(xd, wf, bp, nhwc(res, dtype) if with_res else None, nhwc(aux, dtype) if act == 2 else None, y, ypre,
+                         N, H, W, Cin, H, W, Cout, ks, 1, 0, act, kbf)
+        torch.cuda.synchronize()
+        assert L.mdm_last_gemm_kernel().decode().startswith("conv_gemm_x_kernel"), L.mdm_last_gemm_kernel()
+    finally:
+        L.mdm_dev_set_knob(3, 0)
+    assert relerr(nchw(y), y_ref) < TOL[dtype]
+    if act == 1:
+        assert relerr(nchw(ypre), pre) < TOL[dtype]
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 256, 256), (3, 8, 16, 512, 256), (2, 16, 8, 768, 768)])
 def test_upsample_conv_sub_pixel_form(N, H, W, Cin, Cout):
     """conv3x3(upsample2x(x)) computed from the low-resolution x (mdm_conv_up_fwd: per output phase a 2x2 correlation with

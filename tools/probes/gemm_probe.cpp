@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -130,34 +131,42 @@ int main(int argc, char** argv) {
     // variants: 0 = conv_gemm_bl_kernel, 1 = conv_gemm_x_kernel (super-tile order), then timing-only experiments:
     // 2 = x, row-major tile order; 3 = x, LDS-DMA fetches nothing; 4 = x, barriers do not wait for the DMA; 5 = both;
     // 6 = x without the drain's stores
-    const int NV = 7;
+    // 7 = conv_gemm_bl_kernel with the full wait for its stores before the next tile (dev knob 5: the round-3 behaviour)
+    const int NV = 8;
     double us[NV] = {0};
     char kname[2][96];
-    for (int v = 0; v < NV; ++v) {
-      mdm_dev_set_knob(3, v == 0 ? 1 : 2);
-      mdm_dev_set_knob(4, v == 2 ? 0 : 1);
-      mdm_dev_set_knob(0, v == 3 ? 1 : v == 4 ? 2 : v == 5 ? 3 : 0);
-      mdm_dev_set_knob(1, v == 6 ? 1 : 0);
-      bf16* yy = y[v < 2 ? v : 1 - 1 + 0 * v];   // experiments write into y[0]'s sibling buffer below
-      if (v >= 2) yy = yr;                       // scratch output: the reference rows are computed afterwards
-      bf16* ypp = v < 2 ? yp[v] : ypr;
-      auto run = [&]() {
-        int rc = mdm_conv_fwd(x, w, bias, res, aux, yy, s.act == 1 ? ypp : nullptr, B, s.H, s.H, s.Cin, s.H, s.H, s.Cout, s.ks, 1, 0,
-                              s.act, kblk, 1, st);
-        if (rc) { printf("mdm_conv_fwd rc=%d: %s\n", rc, mdm_last_error()); exit(1); }
-      };
-      for (int i = 0; i < 3; ++i) run();
-      CK(hipStreamSynchronize(st));
-      if (v < 2) strncpy(kname[v], mdm_last_gemm_kernel(), 95);
-      CK(hipEventRecord(e0, st));
-      for (int i = 0; i < iters; ++i) run();
-      CK(hipEventRecord(e1, st));
-      CK(hipStreamSynchronize(st));
-      float ms;
-      CK(hipEventElapsedTime(&ms, e0, e1));
-      us[v] = ms * 1e3 / iters;
-    }
-    mdm_dev_set_knob(0, 0); mdm_dev_set_knob(1, 0); mdm_dev_set_knob(4, 1);
+    // interleaved rounds (variant order rotates; the median of the rounds is reported): a variant timed once, first, right
+    // after the allocations runs 5-10 % slower than the same variant timed later
+    const int ROUNDS = 5;
+    std::vector<double> tv[NV];
+    for (int r = 0; r < ROUNDS; ++r)
+      for (int vi = 0; vi < NV; ++vi) {
+        const int v = (vi + r) % NV;
+        mdm_dev_set_knob(3, (v == 0 || v == 7) ? 1 : 2);
+        mdm_dev_set_knob(5, v == 7 ? 1 : 0);
+        mdm_dev_set_knob(4, v == 2 ? 0 : 1);
+        mdm_dev_set_knob(0, v == 3 ? 1 : v == 4 ? 2 : v == 5 ? 3 : 0);
+        mdm_dev_set_knob(1, v == 6 ? 1 : 0);
+        bf16* yy = v < 2 ? y[v] : yr;              // experiments write into scratch outputs (the reference rows come later)
+        bf16* ypp = v < 2 ? yp[v] : ypr;
+        auto run = [&]() {
+          int rc = mdm_conv_fwd(x, w, bias, res, aux, yy, s.act == 1 ? ypp : nullptr, B, s.H, s.H, s.Cin, s.H, s.H, s.Cout, s.ks, 1, 0,
+                                s.act, kblk, 1, st);
+          if (rc) { printf("mdm_conv_fwd rc=%d: %s\n", rc, mdm_last_error()); exit(1); }
+        };
+        run();
+        CK(hipStreamSynchronize(st));
+        if (v < 2) strncpy(kname[v], mdm_last_gemm_kernel(), 95);
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) run();
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        tv[v].push_back(ms * 1e3 / iters);
+      }
+    for (int v = 0; v < NV; ++v) { std::sort(tv[v].begin(), tv[v].end()); us[v] = tv[v][ROUNDS / 2]; }
+    mdm_dev_set_knob(0, 0); mdm_dev_set_knob(1, 0); mdm_dev_set_knob(4, 1); mdm_dev_set_knob(5, 0);
     mdm_dev_set_knob(3, 0);
     // X vs the 8-wave kernel, every element
     unsigned long long bad[3] = {0, 0, 0};
@@ -179,9 +188,14 @@ int main(int argc, char** argv) {
     compare_rows<<<dim3(nrows, (s.Cout + 127) / 128), 128, 0, st>>>(y[1], yr, M, s.Cout, rstep, 0.03f, 0.03f, d_bad, d_max);
     CK(hipMemcpyAsync(&bad[2], d_bad, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&mr[2], d_max, 4, hipMemcpyDeviceToHost, st));
     CK(hipStreamSynchronize(st));
+    unsigned long long badbl = 0; float mrbl = 0;
+    CK(hipMemsetAsync(d_bad, 0, 8, st)); CK(hipMemsetAsync(d_max, 0, 4, st));
+    compare_rows<<<dim3(nrows, (s.Cout + 127) / 128), 128, 0, st>>>(y[0], yr, M, s.Cout, rstep, 0.03f, 0.03f, d_bad, d_max);
+    CK(hipMemcpyAsync(&badbl, d_bad, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&mrbl, d_max, 4, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
     const double fl = 2.0 * M * s.Cout * K;
-    printf("%-26s M=%-6d N=%-4d K=%-5d | bl %7.1f us %6.0f TF | x %7.1f us %6.0f TF | x/bl %.3f | rowmajor %7.1f | noDMA %7.1f | nowait %7.1f | both %7.1f | nostore %7.1f | vs bl: bad %llu maxrel %.3g%s | vs naive: bad %llu maxrel %.3g | %s / %s\n",
-           s.name, M, s.Cout, K, us[0], fl / us[0] * 1e-6, us[1], fl / us[1] * 1e-6, us[1] / us[0], us[2], us[3], us[4], us[5], us[6], bad[0], mr[0],
+    printf("%-26s M=%-6d N=%-4d K=%-5d | bl %7.1f us %6.0f TF | x %7.1f us %6.0f TF | x/bl %.3f | rowmajor %7.1f | noDMA %7.1f | nowait %7.1f | both %7.1f | nostore %7.1f | bl-oldwait %7.1f | bl vs naive: bad %llu maxrel %.3g | x vs bl: bad %llu maxrel %.3g%s | vs naive: bad %llu maxrel %.3g | %s / %s\n",
+           s.name, M, s.Cout, K, us[0], fl / us[0] * 1e-6, us[1], fl / us[1] * 1e-6, us[1] / us[0], us[2], us[3], us[4], us[5], us[6], us[7], badbl, mrbl, bad[0], mr[0],
            s.act == 1 ? (bad[1] ? " (ypre BAD)" : " (ypre ok)") : "", bad[2], mr[2], kname[0], kname[1]);
     fflush(stdout);
     CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(bias)); CK(hipFree(yr)); CK(hipFree(ypr));
