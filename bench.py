@@ -148,7 +148,7 @@ def cpu_baseline(workload, batch_ref):
     }
 
 
-def make_step(pipe, bf16, world, plain=False, bucket_mb=256.0, wire=None, serial_wgrad=False, force_collectives=False, torch_ddp=False):
+def make_step(pipe, bf16, world, plain=False, bucket_mb=256.0, wire="auto", serial_wgrad=False, force_collectives=False, torch_ddp=False):
     """The objects clis/train_parallel.py:107-154 builds around the pipeline, and the step closure of its loop
     (:216-230): -> (step(sample) -> loss value, optimizer)"""
     import types
@@ -164,7 +164,7 @@ def make_step(pipe, bf16, world, plain=False, bucket_mb=256.0, wire=None, serial
         pipe.model = torch.nn.parallel.DistributedDataParallel(pipe.model, device_ids=[torch.cuda.current_device()])
     elif world > 1 or force_collectives:                                                          # ... or our wrapper in its place
         pipe.model = mdist.DataParallel(pipe.model, device_ids=[torch.cuda.current_device()], bucket_mb=bucket_mb,
-                                        wire_dtype=wire, force_collectives=force_collectives)
+                                        wire_dtype=wire, force_collectives=force_collectives, record_timeline=True)
     ema = trainer.ModelEma(vm)                                                                    # :157
     args = types.SimpleNamespace(fp16=bf16, gradient_clip_norm=2.0)
     scaler = torch.amp.GradScaler("cuda") if bf16 else None                                      # :113-116
@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--no-reference-loop", action="store_true", help="skip the plain-path (torch optimizer / EMA / autograd accumulation) leg")
     ap.add_argument("--reference-loop", action="store_true", help="run the plain-path leg also when N > 1 (torch DDP, as the unchanged CLI)")
     ap.add_argument("--no-nested1024", action="store_true", help="skip the nested-1024 (configs[4]) sampling leg")
+    ap.add_argument("--wire-fp32", action="store_true", help="fp32 gradients on the wire (default with N > 1 over RCCL: bf16)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="N = 1 only: run the gradient buckets through RCCL anyway (world-of-one process group)")
     ap.add_argument("--sample-batch", type=int, default=None)
@@ -234,7 +235,7 @@ def main():
     device = torch.device("cuda", local)
     batch = args.batch or {"unet64": 64, "nested256": 16, "mini": 4}[args.workload]
     bf16 = args.dtype == "bf16"
-    wire = torch.bfloat16 if args.wire_bf16 else None
+    wire = torch.bfloat16 if args.wire_bf16 else (torch.float32 if args.wire_fp32 else "auto")   # auto: bf16 over RCCL when N > 1
 
     def sync():
         if world > 1:
@@ -247,6 +248,13 @@ def main():
     sample = synthetic_batch(batch, side, device, seed=1234 + rank)
     dt = timed_steps(step, sample, args.warmup, args.steps, sync)
     assert getattr(opt, "_mdm_fused", False) not in (None, False), getattr(opt, "_mdm_fused_reason", "the fused path did not engage")
+    # what went over the wire, and when: per bucket of the LAST step (bucket, MB, issued at, compute stream free at; ms from
+    # the first bucket's issue) -- how much of the gradient exchange hid behind backward on this node
+    comm_wire, comm_timeline = "fp32", None
+    red = getattr(pipe.model, "reducer", None)
+    if red is not None:
+        comm_wire = "bf16" if red.wire_dtype == torch.bfloat16 else "fp32"
+        comm_timeline = [[b, round(nb / 1e6, 1), round(t0, 3), round(t1, 3)] for b, nb, t0, t1 in red.timeline()]
     if world > 1:
         tt = torch.tensor([dt], device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -421,7 +429,7 @@ def main():
                 "step_mfma_roofline_frac": round(alg_tflop_step / (ms / 1e3) / (PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS), 4),
                 "comm": {"backend": dist.get_backend() if dist.is_initialized() else None, "world_size": world, "forced_collectives": bool(args.force_collectives),
                          "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.is_initialized() else None,
-                         "bucket_mb": args.bucket_mb, "wire_dtype": "bf16" if args.wire_bf16 else "fp32"},
+                         "bucket_mb": args.bucket_mb, "wire_dtype": comm_wire, "bucket_timeline_ms": comm_timeline},
             },
             "roofline": roof,
             "sampling": samp,

@@ -13,9 +13,19 @@ int mdm_conv_fwd_tile(int M, int Cout, int dtype);
 /* host-only: 128 or 256 (square output tile edge) mdm_conv_wgrad will use */
 int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype);
 
-/* development knobs of the GEMM kernels (all 0 in the product): 1 = epilogues skip their global stores (measures what
- * the store phase costs), 2 = force the forward tile (128128 / 256192 / 256256).  Experiments recorded in DESIGN.md. */
+/* development knobs of the GEMM kernels (all 0 / default in the product; host-side state of the calling process, never
+ * read from the environment inside an entry point).  Experiments recorded in DESIGN.md / profiles/.
+ *   0  conv_gemm_x_kernel: bit 0 = its LDS-DMA fetches nothing, bit 1 = its barriers do not wait for the DMA (timing only)
+ *   1  epilogues skip their global stores (what the store phase costs)
+ *   2  force the forward tile of conv_gemm_bl_kernel (128128 / 256192 / 256256)
+ *   3  conv_gemm_x_kernel: 0 = by the host rule, 1 = never, 2 = whenever the problem allows
+ *   4  conv_gemm_x_kernel tile order: 0 = row-major, 1 = super-tiles (default)
+ *   6  tile-fill percentage below which a forward GEMM may split its reduction (default 80; 25 = the sampling-only rule)
+ *   7  1 = the narrow 3x3 convolutions of the nested models go back to the implicit-GEMM kernel (no conv3x3_direct_kernel) */
 int mdm_dev_set_knob(int idx, int value);
+/* attention backward kernel choice: 0 = by shape, 1 = always the split (dQ + dK/dV) kernels, 2 = the one-block-per-head
+ * kernel whenever the shape allows (tests) */
+int mdm_dev_set_attn_bwd(int mode);
 
 #ifdef __cplusplus
 }

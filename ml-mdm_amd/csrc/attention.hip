@@ -1226,6 +1226,15 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   MDM_LAUNCH_STATUS();
 }
 
+// development knob (mdm_hip_dev.h), read by mdm_attn_bwd's kernel choice; a plain int set from the host thread that
+// drives the experiment -- no environment lookups inside the boundary's entry points
+static int g_attn_bwd_mode = 0;
+extern "C" int mdm_dev_set_attn_bwd(int mode) {
+  if (mode < 0 || mode > 2) return -1;
+  g_attn_bwd_mode = mode;
+  return 0;
+}
+
 template <typename T, int D>
 static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int dc_rs, hipStream_t st) {
   using G = AttnGeom<T, D>;
@@ -1244,10 +1253,10 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
   a.dkc = dkc; a.dvc = dvc; a.dkc_bs = dc_bs; a.dkc_rs = dc_rs;
   if constexpr (sizeof(T) == 2) {
     // short sequences: one block per (batch, head), operands LDS-resident (attn_bwd_small_kernel)
-    // MDM_HIP_ATTN_BWD = "split" (never) / "small" (whenever the shape allows; the tests) overrides the choice below
-    const char* const mode_env = getenv("MDM_HIP_ATTN_BWD");
-    const bool split_only = mode_env && mode_env[0] == 's' && mode_env[1] == 'p';
-    const bool force_small = mode_env && mode_env[0] == 's' && mode_env[1] == 'm';
+    // development knob mdm_dev_set_attn_bwd (include/mdm_hip_dev.h): 1 = "split" (never), 2 = "small" (whenever the shape
+    // allows; the tests) override the choice below; 0 in the product
+    const bool split_only = g_attn_bwd_mode == 1;
+    const bool force_small = g_attn_bwd_mode == 2;
     // (one block per head: worth it once the heads fill the chip -- at batch 16 the 128 blocks of the 64x64 U-Net's
     // 16x16 level would leave half the CUs idle, and the streaming kernels' 4 + 5 blocks per head win)
     if (a.L <= 256 && (!a.kc || a.S <= 64) && (a.B * a.H >= device_cus() || force_small) && !split_only) {

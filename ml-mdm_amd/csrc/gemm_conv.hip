@@ -2061,9 +2061,11 @@ static bool conv_bl_ok(const ConvArgs& a) {
 // k-tiles of serial walk (~10 us) -- the second launch costs about that much.  1 = do not split.
 // Considered whenever the tiles fill less than `fill` percent of the 2-per-CU slots: 80 also catches the training shapes
 // of the nested model's inner U-Net at batch 16 (M = 4096: 192 tiles of 128x128 at N = 768), 25 was the sampling-only rule.
+static int g_split_fill = 80;   // development knob 6
+static int g_no_direct = 0;     // development knob 7: 1 = narrow 3x3 convolutions back on the implicit-GEMM kernel
 static int conv_ksplit(int M, int Cout, int K, int dtype) {
   if (dtype != DT_BF16 || K % 64 != 0 || Cout % 8 != 0 || Cout <= 64) return 1;
-  static const int fill = getenv("MDM_HIP_SPLIT_FILL") ? atoi(getenv("MDM_HIP_SPLIT_FILL")) : 80;
+  const int fill = g_split_fill;   // development knob 6 (mdm_dev_set_knob), default 80
   const long tiles = (long)((M + 127) / 128) * ((Cout + 127) / 128);
   const int nt = K / 64, cus = device_cus();
   if (tiles * 100 > (long)fill * 2 * cus || nt < 12) return 1;
@@ -2283,8 +2285,7 @@ static int launch_conv_direct(const ConvArgs& a, hipStream_t st) {
 
 // usable for this problem?  (bf16, 3x3 stride 1, plain epilogue, 32 / 64 channels both sides, tile-aligned image)
 static bool conv_direct_ok(const ConvArgs& a, int ksize, int transposed, int dtype) {
-  static const int off = getenv("MDM_HIP_CONV_DIRECT") ? atoi(getenv("MDM_HIP_CONV_DIRECT")) == 0 : 0;
-  if (off || dtype != DT_BF16 || ksize != 3 || transposed || a.stride != 1 || a.act != 0 || a.aux || a.ypre) return false;
+  if (g_no_direct || dtype != DT_BF16 || ksize != 3 || transposed || a.stride != 1 || a.act != 0 || a.aux || a.ypre) return false;
   if (!(a.Cin == 32 || a.Cin == 64) || !(a.Cout == 32 || a.Cout == 64)) return false;
   if (a.kblk != 0 && !(a.kblk == 64 && a.Cin == 64)) return false;      // [Cout][tap][Cin] either way
   if (a.Ho != a.H || a.Wo != a.W || a.H % 8 != 0 || a.W % 64 != 0) return false;
@@ -2584,8 +2585,10 @@ extern "C" int mdm_linear_grouped(const void* const* x, const void* const* w_pac
 }
 
 extern "C" int mdm_dev_set_knob(int idx, int value) {
-  MDM_CHECK_ARG(idx >= 0 && idx < 5);
+  MDM_CHECK_ARG(idx >= 0 && idx < 8);
   if (idx == 3) { g_force_x = value; return 0; }
+  if (idx == 6) { g_split_fill = value > 0 ? value : 80; return 0; }
+  if (idx == 7) { g_no_direct = value; return 0; }
   if (idx == 2) g_force_tile = value;
   if (idx == 4) { g_x_order = value; return 0; }
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdm::g_knobs), &value, sizeof(int), idx * sizeof(int));

@@ -123,8 +123,23 @@ def lib():
         if handle.mdm_abi_version() != ABI_VERSION:
             raise MdmHipError("libmdm_hip.so was built for ABI %d, include/mdm_hip.h declares %d: rebuild (__graft_entry__.build())"
                               % (handle.mdm_abi_version(), ABI_VERSION))
+        _apply_dev_env(handle)
         _lib = handle
     return _lib
+
+
+def _apply_dev_env(handle):
+    """Development A/B switches: environment variables of THIS Python layer, applied once through the setters of
+    include/mdm_hip_dev.h -- the C entry points themselves never look at the environment."""
+    mode = os.environ.get("MDM_HIP_ATTN_BWD")
+    if mode:
+        handle.mdm_dev_set_attn_bwd({"split": 1, "small": 2}.get(mode, 0))
+    if os.environ.get("MDM_HIP_SPLIT_FILL"):
+        handle.mdm_dev_set_knob(6, int(os.environ["MDM_HIP_SPLIT_FILL"]))
+    if os.environ.get("MDM_HIP_CONV_DIRECT") == "0":
+        handle.mdm_dev_set_knob(7, 1)
+    if os.environ.get("MDM_HIP_GEMM_X") in ("0", "2"):   # 0: never conv_gemm_x_kernel, 2: whenever it can
+        handle.mdm_dev_set_knob(3, 1 if os.environ["MDM_HIP_GEMM_X"] == "0" else 2)
 
 
 def check(rc: int, what: str):

@@ -16,7 +16,13 @@ torch DDP's reducer with a design sized for 8 x MI355X on point-to-point xGMI li
     optimizer.  Optional bf16 wire format halves the bytes;
   * the LAST bucket (the first layers of the network: their gradients arrive when backward ends, so
     nothing is left to hide its all-reduce behind) is kept small (``tail_mb``, default 8 MiB): the
-    exposed tail of the communication is one sub-millisecond collective, not a 256 MiB one.
+    exposed tail of the communication is one sub-millisecond collective, not a 256 MiB one;
+  * the FIRST bucket is small too (``head_mb``, default 64 MiB = 4 % of the 64x64 U-Net's 1.66 GB of gradients): the
+    links start working within the first tenth of backward instead of after a full 256 MiB has accumulated;
+  * with more than one rank the wire format defaults to bf16 (``wire_dtype="auto"``): half the bytes per link, fp32
+    accumulation on arrival (pass ``torch.float32`` for an fp32 wire);
+  * ``record_timeline=True`` stamps every bucket's issue and completion with HIP events (``timeline()``), so the first
+    run on a multi-GPU node shows how much of the exchange hid behind backward (``bench.py --gpus N`` prints it).
 
 Unmeasured on hardware: the build environment exposes one GPU, so the 1 -> 8 scaling curve is the
 driver's to measure; the code path is exercised by gloo world-2 tests on CPU and a 2-rank shared-GPU test.
@@ -70,8 +76,9 @@ class GradReducer:
     in a world of one -- the RCCL code path (async all-reduce on arena views, stream ordering, bf16 wire copy-back) can
     then be exercised on a single GPU (``bench.py --force-collectives``)."""
 
-    def __init__(self, params, bucket_mb: float = 256.0, wire_dtype: torch.dtype = None, group=None, tail_mb: float = 8.0,
-                 world_override: int = None, force_collectives: bool = False):
+    def __init__(self, params, bucket_mb: float = 256.0, wire_dtype="auto", group=None, tail_mb: float = 8.0,
+                 world_override: int = None, force_collectives: bool = False, head_mb: float = 64.0,
+                 record_timeline: bool = False):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.nranks = dist.get_world_size(group) if dist.is_initialized() else 1   # divisor of the average
@@ -79,7 +86,16 @@ class GradReducer:
             self.nranks = int(world_override)
         # ``world`` > 1 switches the hooks / buckets / collectives on (a forced single-rank run pretends 2)
         self.world = self.nranks if not (force_collectives and self.nranks == 1 and dist.is_initialized()) else 2
+        if isinstance(wire_dtype, str):
+            if wire_dtype != "auto":
+                raise ValueError("wire_dtype: a torch dtype, None (fp32) or 'auto'")
+            # bf16 on the wire whenever there IS a wire (and the backend is a GPU one: gloo reduces bf16 slowly)
+            nccl = dist.is_initialized() and str(dist.get_backend(group)).lower() == "nccl"
+            wire_dtype = torch.bfloat16 if (self.nranks > 1 and nccl and self.params and self.params[0].is_cuda) else None
         self.wire_dtype = wire_dtype
+        self.record_timeline = bool(record_timeline)
+        self._timeline = []        # (bucket, bytes on the wire, issue event, done event) of the current step
+        self._t0 = None
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -87,6 +103,7 @@ class GradReducer:
         order = list(reversed(self.params))
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
         tail = min(int(tail_mb * (1 << 20) / 4), cap)
+        head = max(1, min(int(head_mb * (1 << 20) / 4), cap)) if head_mb else cap
         # index of the first parameter of the tail bucket: the longest suffix of `order` that fits tail_mb
         tail_from, acc = len(order), 0
         for i in range(len(order) - 1, -1, -1):
@@ -105,7 +122,7 @@ class GradReducer:
             p.grad = self.flat[off:off + n].view_as(p)
             self._bucket_of[p] = len(self.buckets)
             off += n
-            if off - b_start >= cap:
+            if off - b_start >= (head if not self.buckets else cap):
                 self.buckets.append((b_start, off))
                 b_start = off
         if off > b_start:
@@ -179,15 +196,26 @@ class GradReducer:
     def _launch(self, b):
         s, e = self.buckets[b]
         buf = self.flat[s:e]
+        ev = None
+        if self.record_timeline and buf.is_cuda:
+            if self._t0 is None:   # first bucket of the step: the clock starts at the first issue
+                self._t0 = torch.cuda.Event(enable_timing=True)
+                self._t0.record()
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
         if self.wire_dtype is not None and self.wire_dtype != torch.float32:
             wire = buf.to(self.wire_dtype)
             wire.div_(self.nranks)
             h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._work.append((h, buf, wire))
+            nbytes = wire.numel() * wire.element_size()
         else:
             buf.div_(self.nranks)  # pre-scale: SUM of pre-divided == AVG, and gloo has no AVG
             h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._work.append((h, None, None))
+            nbytes = buf.numel() * 4
+        if ev is not None:
+            self._timeline.append([b, nbytes, ev, None])
 
     def no_sync(self):
         """context manager for gradient-accumulation micro-steps (train_parallel.py:201-203)"""
@@ -223,14 +251,30 @@ class GradReducer:
                 lost = [(i, tuple(p.shape), self._fired.get(id(p), 0)) for i, p in enumerate(self.params) if self._fired.get(id(p), 0) != 1]
                 raise RuntimeError("buckets %s did not receive all their gradients; parameters (index, shape) that "
                                    "did not report exactly once (index, shape, count): %s" % (missing, lost[:12]))
-            for h, buf, wire in self._work:
+            for i, (h, buf, wire) in enumerate(self._work):
                 h.wait()
                 if wire is not None:
                     buf.copy_(wire)
+                if self.record_timeline and i < len(self._timeline) and self._timeline[i][3] is None:
+                    done = torch.cuda.Event(enable_timing=True)
+                    done.record()   # on the compute stream, right behind its wait for this bucket's collective
+                    self._timeline[i][3] = done
             self._work = []
+            if self.record_timeline:
+                self._last_timeline, self._last_t0 = self._timeline, self._t0
+                self._timeline, self._t0 = [], None
             self._pending = list(self._need)
             self._fired = {}
         self._deferred = set()
+
+    def timeline(self):
+        """[(bucket, wire bytes, issue ms, done ms)] of the last finished step, relative to its first issue; ``done`` is
+        when the compute stream could proceed past the bucket (record_timeline=True; synchronises the device)"""
+        tl, t0 = getattr(self, "_last_timeline", None), getattr(self, "_last_t0", None)
+        if not tl or t0 is None:
+            return []
+        torch.cuda.synchronize()
+        return [(b, nb, t0.elapsed_time(e0), t0.elapsed_time(e1) if e1 is not None else float("nan")) for b, nb, e0, e1 in tl]
 
     def zero_grad(self):
         self.flat.zero_()
@@ -266,13 +310,30 @@ class DataParallel(torch.nn.Module):
     a ``GradReducer`` over the vision model's parameters (flat arena, large buckets, tail bucket) instead of DDP's
     25 MiB bucket copies, and rank 0's parameters are broadcast at wrap time like DDP does."""
 
-    def __init__(self, module, device_ids=None, bucket_mb: float = 256.0, wire_dtype: torch.dtype = None, tail_mb: float = 8.0,
-                 force_collectives: bool = False, **unused):
+    # DistributedDataParallel keywords that change nothing here (accepted and ignored) ...
+    _IGNORED = {"output_device", "dim", "broadcast_buffers", "process_group", "bucket_cap_mb", "check_reduction",
+                "gradient_as_bucket_view", "init_sync", "device_mesh", "mixed_precision", "delay_all_reduce_named_params",
+                "param_to_hook_all_reduce"}
+    # ... and the ones whose semantics this reducer does not have: every parameter must receive exactly one gradient per
+    # synchronised backward (finish() raises otherwise), so an "unused parameters" search or a frozen graph cannot be honoured
+    _UNSUPPORTED = {"find_unused_parameters", "static_graph"}
+
+    def __init__(self, module, device_ids=None, bucket_mb: float = 256.0, wire_dtype="auto", tail_mb: float = 8.0,
+                 force_collectives: bool = False, head_mb: float = 64.0, record_timeline: bool = False, **ddp_kwargs):
         super().__init__()
+        for k, v in ddp_kwargs.items():
+            if k in self._UNSUPPORTED:
+                if v:
+                    raise ValueError("mdm_hip.distributed.DataParallel does not implement %s=True: every parameter of the "
+                                     "vision model must receive a gradient in every synchronised backward" % k)
+            elif k not in self._IGNORED:
+                raise TypeError("DataParallel got an unexpected keyword argument %r" % k)
+        if ddp_kwargs.get("process_group") is not None:
+            raise ValueError("process_group: pass the group to GradReducer directly (the default group is used here)")
         self.module = module
         net = getattr(module, "vision_model", module)
         self.reducer = GradReducer(list(net.parameters()), bucket_mb=bucket_mb, wire_dtype=wire_dtype, tail_mb=tail_mb,
-                                   force_collectives=force_collectives)
+                                   force_collectives=force_collectives, head_mb=head_mb, record_timeline=record_timeline)
         self.reducer.broadcast_parameters(0)
 
     def forward(self, *args, **kwargs):

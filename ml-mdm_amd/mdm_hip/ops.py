@@ -957,6 +957,9 @@ class GroupNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, beta, film, stats, coef)
         ctx.groups, ctx.act = groups, act
         ctx.passthrough = passthrough
+        # an unused pass-through output (the skip tap of a block whose activations nobody collects) must reach backward
+        # as None, not as a materialised zero tensor that costs an allocation, a memset and a read pass of the kernel
+        ctx.set_materialize_grads(False)
         if passthrough == 2:
             # third output = x once more, for a consumer OUTSIDE the block (the U-Net's skip connection): its gradient
             # arrives as dres2 and is added in the same kernel -- no accumulation kernel of the autograd engine
@@ -970,6 +973,8 @@ class GroupNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dres=None, dres2=None):
         x, gamma, beta, film, stats, coef = ctx.saved_tensors
+        if dy is None:                       # only the pass-through outputs were used
+            dy = torch.zeros_like(x)
         dx, dgamma, dbeta, dfilm = _gn_backward(dy, x, gamma, beta, film, stats, coef, dres, dres2, ctx.groups, ctx.act)
         return dx, dgamma, dbeta, dfilm, None, None, None, None
 

@@ -38,7 +38,7 @@ class FusedState:
     """Flat fp32 arenas for parameters / gradients / Adam moments / EMA of one vision model, and the fused optimizer
     tail over them.  Arena order = reverse registration order (the order backward produces gradients)."""
 
-    def __init__(self, net, reducer=None, bucket_mb=256.0, wire_dtype=None, use_ema=True, async_wgrad=True):
+    def __init__(self, net, reducer=None, bucket_mb=256.0, wire_dtype="auto", use_ema=True, async_wgrad=True):
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.reducer = reducer if reducer is not None else GradReducer(self.params, bucket_mb=bucket_mb, wire_dtype=wire_dtype)
@@ -102,6 +102,12 @@ def _adopt(model, optimizer, ema_model):
     combination does not qualify for the fused path (see the module docstring)."""
     st = getattr(optimizer, "_mdm_fused", None)
     if st is not None:
+        if st is not False and st.ema_id != (id(ema_model) if ema_model is not None else None):
+            # the EMA arena was wired (or left out) at adoption: a different / late ModelEma would silently never update
+            raise RuntimeError("train_batch was first called %s and now %s: pass the same ema_model on every call "
+                               "(the fused step adopted it together with the optimizer)"
+                               % ("without an ema_model" if st.ema_id is None else "with another ema_model",
+                                  "without one" if ema_model is None else "with one"))
         return st if st is not False else None
 
     def no(reason):
@@ -159,12 +165,33 @@ def _adopt(model, optimizer, ema_model):
         for p in params:
             optimizer.state[p]["step"] = step_host
         optimizer.register_state_dict_pre_hook(lambda opt, st=st, t=step_host: t.fill_(float(int(st.step_dev))))
+
+        def _reinstall(opt, st=st, params=params, t=step_host):
+            # optimizer.load_state_dict() replaced the state entries with fresh tensors: copy them into the arenas the
+            # fused kernel reads and put the views (and the shared step tensor) back
+            with torch.no_grad():
+                steps_ = 0
+                for p_ in params:
+                    ent = opt.state.get(p_)
+                    if not ent or "exp_avg" not in ent:
+                        continue
+                    mv_, vv_ = st.view(st.m, p_), st.view(st.v, p_)
+                    if ent["exp_avg"].data_ptr() != mv_.data_ptr():
+                        mv_.copy_(ent["exp_avg"])
+                        vv_.copy_(ent["exp_avg_sq"])
+                    steps_ = max(steps_, int(ent["step"]))
+                    opt.state[p_] = {"step": t, "exp_avg": mv_, "exp_avg_sq": vv_}
+                st.step_dev.fill_(steps_)
+                t.fill_(float(steps_))
+
+        optimizer.register_load_state_dict_post_hook(_reinstall)
         if ema_net is not None:
             by_name = dict(net.named_parameters())
             for name, pe in ema_net.named_parameters():
                 ev = st.view(st.flat_ema, by_name[name])
                 ev.copy_(pe.detach())
                 pe.data = ev
+    st.ema_id = id(ema_model) if ema_model is not None else None
     optimizer._mdm_fused = st
     return st
 
@@ -181,7 +208,18 @@ def train_batch(model, sample, optimizer, scheduler, logger, args, grad_scaler=N
     model.train()
     lr = scheduler.get_last_lr()[0]
     st = _adopt(model, optimizer, ema_model)
+    if st is None and isinstance(model.model, DataParallel):
+        # the plain path drives torch's own pieces (clip_grad_norm_, optimizer.step(), optimizer.zero_grad()): nothing in
+        # it joins this wrapper's asynchronous all-reduces or keeps p.grad inside its arena -- ranks would diverge silently
+        raise RuntimeError("mdm_hip.distributed.DataParallel only works with the fused train step, which this call cannot "
+                           "take: %s.  Use torch.optim.AdamW / Adam (one parameter group, no amsgrad) with a ModelEma on "
+                           "the model's device, or wrap the model in torch.nn.parallel.DistributedDataParallel instead."
+                           % getattr(optimizer, "_mdm_fused_reason", "?"))
     fp16 = bool(getattr(args, "fp16", False))
+    # several ranks in a synchronised fused step: a NaN loss on ONE rank must not change that rank's host-side sequence
+    # (scheduler.step(), EMA warm-up counter) -- every rank runs backward and the common tail, the update is skipped on
+    # the device by all of them (the reduced gradient norm is not finite), and the NaN is reported through loss_val
+    lockstep = st is not None and st.reducer.world > 1 and not accumulate_gradient
     dev_type = "cuda" if next(_vision_model(model).parameters()).is_cuda else "cpu"
     if st is not None and ops._grad_sink is not st.reducer:
         st.activate()   # another FusedState (a second model in the same process) was used in between
@@ -191,7 +229,7 @@ def train_batch(model, sample, optimizer, scheduler, logger, args, grad_scaler=N
             losses, times, x_t, means, targets, weights = model.get_loss(sample)
             loss = _loss_of(losses, weights) * loss_factor
             loss_val = loss.item()
-            if math.isnan(loss_val):
+            if math.isnan(loss_val) and not lockstep:
                 _skip_step(st, optimizer, loss, accumulate_gradient, args, fp16)
                 return loss_val, losses, times, x_t, means, targets
             if num_grad_accumulations != 1:
@@ -204,7 +242,7 @@ def train_batch(model, sample, optimizer, scheduler, logger, args, grad_scaler=N
         losses, times, x_t, means, targets, weights = model.get_loss(sample)
         loss = _loss_of(losses, weights)
         loss_val = loss.item()
-        if math.isnan(loss_val):
+        if math.isnan(loss_val) and not lockstep:
             _skip_step(st, optimizer, loss, accumulate_gradient, args, fp16)
             if st is None:
                 optimizer.step()
@@ -253,20 +291,13 @@ def train_batch(model, sample, optimizer, scheduler, logger, args, grad_scaler=N
 
 
 def _skip_step(st, optimizer, loss, accumulate_gradient, args, fp16):
-    """NaN loss: drop the gradients accumulated so far and take no step (reference trainer.py:38-41, 64-69).  With
-    several ranks in a synchronised step the reference's early return deadlocks the ranks that did not see the NaN (they
-    wait for bucket all-reduces the returning rank never issues); here every rank still runs backward and the fused
-    optimizer, which skips the update ON THE DEVICE when the reduced gradient norm is not finite -- the same outcome
-    (no update, gradients cleared, step number not advanced) without a host-side branch that could diverge."""
+    """NaN loss: drop the gradients accumulated so far and take no step (reference trainer.py:38-41, 64-69).  Only
+    reached where no other rank depends on this one's sequence (one rank, the plain path, or an accumulation micro-step
+    under no_sync()); in a synchronised multi-rank fused step train_batch does NOT return early -- with the reference's
+    per-rank early return the other ranks wait for bucket all-reduces that never come, and a rank that skips
+    scheduler.step() / the EMA counter trains on another learning rate from then on."""
     if st is None:
         optimizer.zero_grad()
-        return
-    if st.reducer.world > 1 and not accumulate_gradient:
-        loss.backward()
-        st.finish_backward()
-        grp = optimizer.param_groups[0]
-        st.optimizer_step(grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"], float(getattr(args, "gradient_clip_norm", 2.0)),
-                          1.0, torch.bfloat16 if fp16 else torch.float32)
         return
     st.finish_backward()    # nothing may still be adding into the arena
     st.reducer.zero_grad()

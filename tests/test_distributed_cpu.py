@@ -195,3 +195,103 @@ def test_single_process_reducer_is_a_noop():
     assert all(p.grad.data_ptr() >= red.flat.data_ptr() for p in model.parameters())
     red.zero_grad()
     assert float(red.flat.abs().max()) == 0.0
+
+
+def _w4_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml-mdm_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mdm_hip import distributed as md
+
+    md.init_distributed_singlenode(backend="gloo")
+    model = _model(seed=rank)
+    # bucket sizes that cut the arena at uneven places: a head bucket of one bias-sized parameter (it closes as soon as it
+    # is exceeded), 2.2 KB regular buckets that close in the middle of a layer's (weight, bias) pair, the tail bucket = first layer
+    red = md.GradReducer(list(model.parameters()), bucket_mb=0.0021, head_mb=0.00002, tail_mb=0.0045)
+    assert red.wire_dtype is None          # "auto": no bf16 wire over gloo / on CPU tensors
+    red.broadcast_parameters(0)
+    g = torch.Generator().manual_seed(7)
+    x_all, y_all = torch.randn(16, 16, generator=g), torch.randn(16, 8, generator=g)
+    for step in range(3):
+        ((model(x_all[rank::world]) - y_all[rank::world]) ** 2).mean().backward()
+        red.finish()
+        flat = red.flat.clone()
+        red.zero_grad()
+    if rank == 0:
+        torch.save({"flat": flat, "buckets": red.buckets}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_gloo_world4_uneven_buckets(tmp_path):
+    """four ranks, three steps; head / regular / tail buckets of different sizes whose boundaries fall inside and between
+    layers: every bucket fires once per step and finish() returns the average over the four ranks"""
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_w4_worker, args=(4, _free_port(), out), nprocs=4, join=True)
+    got = torch.load(out)
+    model = _model(seed=0)
+    g = torch.Generator().manual_seed(7)
+    x_all, y_all = torch.randn(16, 16, generator=g), torch.randn(16, 8, generator=g)
+    params = list(model.parameters())
+    gs = []
+    for r in range(4):
+        loss = ((model(x_all[r::4]) - y_all[r::4]) ** 2).mean()
+        gs.append(torch.cat([t.reshape(-1) for t in reversed(torch.autograd.grad(loss, params))]))
+    expect = sum(gs) / 4
+    assert torch.allclose(got["flat"], expect, atol=1e-5 * float(expect.abs().max()))
+    sizes = [e - s for s, e in got["buckets"]]
+    assert len(sizes) >= 4 and sizes[0] == 8                   # the head bucket: the last layer's bias alone
+    assert sizes[-1] == 16 * 64 + 64                            # the tail bucket: the first layer
+    assert len(set(sizes)) >= 3 and sum(sizes) == expect.numel()
+
+
+def test_data_parallel_keyword_arguments():
+    """DistributedDataParallel keywords: the harmless ones are accepted, find_unused_parameters / static_graph are refused
+    with a message (the reducer needs a gradient for every parameter), anything else is a TypeError"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml-mdm_amd"))
+    from mdm_hip import distributed as md
+
+    m = _model()
+    wrapped = md.DataParallel(m, device_ids=[0], output_device=0, broadcast_buffers=False, gradient_as_bucket_view=True,
+                              find_unused_parameters=False)
+    assert wrapped.module is m and len(wrapped.reducer.buckets) >= 1
+    with pytest.raises(ValueError, match="find_unused_parameters"):
+        md.DataParallel(_model(), find_unused_parameters=True)
+    with pytest.raises(ValueError, match="static_graph"):
+        md.DataParallel(_model(), static_graph=True)
+    with pytest.raises(TypeError):
+        md.DataParallel(_model(), no_such_option=1)
+
+
+def test_train_batch_refuses_data_parallel_on_the_plain_path():
+    """mdm_hip.distributed.DataParallel around a model whose step cannot take the fused path (here: CPU tensors): the plain
+    path would neither join the wrapper's all-reduces nor keep p.grad in its arena, so train_batch raises instead of
+    letting the ranks drift apart"""
+    import types
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml-mdm_amd"))
+    from mdm_hip import distributed as md
+    from mdm_hip import trainer
+
+    class Vision(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(4, 4)
+
+    class Inner(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.vision_model = Vision()
+
+    class Diffusion(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = md.DataParallel(Inner())
+
+        def get_loss(self, sample):
+            raise AssertionError("must not get this far")
+
+    model = Diffusion()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 1.0)
+    with pytest.raises(RuntimeError, match="only works with the fused train step"):
+        trainer.train_batch(model, {}, opt, sched, None, types.SimpleNamespace(fp16=False))

@@ -504,11 +504,12 @@ def _attn_ref(qkv, kvc, mask, heads):
     (2, 136, 0, 2, 96, False),        # no cross attention, second 128-key / 128-query pass partial
     (40, 64, 8, 8, 32, True),         # B * H = 320 blocks: more heads than CUs (second round of blocks)
 ])
-def test_attention(dtype, B, L, S, H, d, masked, monkeypatch):
-    from mdm_hip import ops
+def test_attention(dtype, B, L, S, H, d, masked, request):
+    from mdm_hip import _lib, ops
 
     # the library picks the one-block-per-head backward only when B * H fills the chip: force it for the small cases
-    monkeypatch.setenv("MDM_HIP_ATTN_BWD", "small")
+    _lib.lib().mdm_dev_set_attn_bwd(2)
+    request.addfinalizer(lambda: _lib.lib().mdm_dev_set_attn_bwd(0))
 
     g = torch.Generator().manual_seed(6)
     C = H * d
@@ -538,7 +539,7 @@ def test_attention(dtype, B, L, S, H, d, masked, monkeypatch):
         assert relerr(kd.grad.float().cpu(), kvc.grad) < tol
     if dtype == torch.bfloat16 and L <= 256 and S <= 64:
         # ... and the two streaming kernels on the same case: both backward paths must agree with the reference
-        monkeypatch.setenv("MDM_HIP_ATTN_BWD", "split")
+        _lib.lib().mdm_dev_set_attn_bwd(1)
         qd2 = qkv.detach().to(dtype).to(dev()).requires_grad_()
         kd2 = kvc.detach().to(dtype).to(dev()).requires_grad_() if S else None
         ops.attention(qd2, kd2, md, H).backward(go.to(dtype).to(dev()))

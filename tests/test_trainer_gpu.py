@@ -143,6 +143,38 @@ def test_objects_the_cli_keeps_using_still_work(tmp_path):
     ops.set_grad_sink(None)
 
 
+def test_adoption_guards_ema_and_reloaded_optimizer_state():
+    """(advisor, round 3) the adoption is cached on the optimizer: a ModelEma that appears (or changes) later must not be
+    silently ignored, and optimizer.load_state_dict() AFTER adoption must reach the arenas the fused kernel reads"""
+    from mdm_hip import ops, trainer
+
+    res, (pipe, opt, ema) = _drive("fused", n_micro=4)
+    vm = pipe.model.vision_model
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 1.0)
+    args = types.SimpleNamespace(fp16=False, gradient_clip_norm=0.5)
+    with pytest.raises(RuntimeError, match="same ema_model"):
+        trainer.train_batch(pipe, _sample(), opt, sched, None, args, ema_model=None)
+    with pytest.raises(RuntimeError, match="same ema_model"):
+        trainer.train_batch(pipe, _sample(), opt, sched, None, args, ema_model=trainer.ModelEma(vm))
+    # load a state dict with recognisable moments: the views are re-installed and the arenas hold the loaded values
+    st = opt._mdm_fused
+    sd = opt.state_dict()
+    for ent in sd["state"].values():
+        ent["exp_avg"] = torch.full_like(ent["exp_avg"], 0.25)
+        ent["exp_avg_sq"] = torch.full_like(ent["exp_avg_sq"], 0.5)
+        ent["step"] = torch.tensor(7.0)
+    opt.load_state_dict(sd)
+    assert float(st.m.min()) == 0.25 and float(st.m.max()) == 0.25 and float(st.v.min()) == 0.5
+    assert int(st.step_dev) == 7
+    p0 = next(iter(vm.parameters()))
+    assert opt.state[p0]["exp_avg"].data_ptr() == st.view(st.m, p0).data_ptr()
+    assert float(opt.state_dict()["state"][0]["step"]) == 7.0
+    trainer.train_batch(pipe, _sample(), opt, sched, None, args, ema_model=ema)   # and the step still runs on them
+    torch.cuda.synchronize()
+    assert int(st.step_dev) == 8 and float(st.m.max()) < 0.25 + 1e-6 and float((st.m - 0.25).abs().max()) > 0
+    ops.set_grad_sink(None)
+
+
 # ---- two ranks on one GPU ------------------------------------------------------------------------------------
 def _free_port():
     s = socket.socket()
@@ -201,3 +233,58 @@ def test_two_ranks_wrapped_like_the_cli_match_one_process(tmp_path, kind):
     one = _rank_run("fused", slice(0, 4), None)
     assert _agg(two["m"], one["m"]) < 1e-4
     assert _agg(two["p"], one["p"]) < 1e-4 and _agg(two["ema"], one["ema"]) < 1e-4
+
+
+def _nan_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    for p in (os.path.join(ROOT, "ml-mdm_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from mdm_hip import distributed as md
+    from mdm_hip import ops, trainer
+
+    md.init_distributed_singlenode(backend="gloo")
+    ops.set_grad_sink(None)
+    pipe = _pipe()
+    vm = pipe.model.vision_model
+    opt = torch.optim.AdamW(vm.parameters(), lr=1e-3, weight_decay=0, eps=1e-8)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: min(1.0, (it + 1) / 4))
+    pipe.model = md.DataParallel(pipe.model, device_ids=[0], bucket_mb=0.25)
+    ema = trainer.ModelEma(vm, decay=0.9, warmup_steps=2)
+    args = types.SimpleNamespace(fp16=True, gradient_clip_norm=0.5)
+    b = _four()
+    smp = {k: b[k][rank * 2:rank * 2 + 2].cuda() for k in ("images", "lm_outputs", "lm_mask")}
+    vals = []
+    for i in range(3):
+        s_i = dict(smp)
+        if i == 1 and rank == 1:   # only rank 1 sees a NaN loss, in the second step
+            s_i["images"] = smp["images"].clone()
+            s_i["images"][0, 0, 0, 0] = float("nan")
+        torch.manual_seed(100 + i)
+        vals.append(trainer.train_batch(pipe, s_i, opt, sched, None, args, ema_model=ema)[0])
+    torch.cuda.synchronize()
+    st = opt._mdm_fused
+    res = {"loss": vals, "lr": sched.get_last_lr()[0], "ema_counter": ema.counter, "step": int(st.step_dev),
+           "p": st.flat_p.detach().cpu().clone()}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_nan_on_one_rank_keeps_the_ranks_in_lockstep(tmp_path):
+    """(advisor, round 3) bf16 fused step on two ranks, a NaN loss on rank 1 only: both ranks must skip the update (device
+    side), keep identical parameters, and advance scheduler and EMA counter identically -- the reference's per-rank early
+    return (trainer.py:38-41) would deadlock DDP, and an early return that skips scheduler.step() desynchronises the lr"""
+    import math
+
+    out = str(tmp_path / "r.pt")
+    mp.spawn(_nan_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out, weights_only=False)
+    assert math.isnan(r1["loss"][1]) and not math.isnan(r0["loss"][1])
+    assert r0["lr"] == r1["lr"] and r0["ema_counter"] == r1["ema_counter"] == 3
+    assert r0["step"] == r1["step"] == 2          # the NaN step did not advance the optimizer
+    assert torch.equal(r0["p"], r1["p"]) and bool(torch.isfinite(r0["p"]).all())
