@@ -15,6 +15,10 @@
  *   - `dtype` selects the storage type of activations / packed weights:
  *       MDM_F32 (0)  exact-fp32 MFMA path (v_mfma_f32_16x16x4_f32)  -- parity mode
  *       MDM_BF16 (1) bf16 storage, fp32 accumulate (v_mfma_f32_16x16x32_bf16)
+ *       MDM_F32_SPLIT (2; mdm_conv_fwd, mdm_conv_fwd_ws, mdm_attn_fwd only) fp32 storage and accumulators, every product
+ *                    as three bf16 MFMAs on bf16 hi + lo halves of the fp32 operands (x*y to ~2^-16 relative): the
+ *                    reference samples in fp32 (diffusion.py:181-197, clis/generate_sample.py:230-256); this is that
+ *                    precision class (1e-3 sampling gate) at about a third of the bf16 rate instead of 1/16
  *     parameters, their gradients, normalisation statistics and LSEs are always fp32
  *   - activations are NHWC: [N, H, W, C] (a linear layer is N=rows, H=W=1)
  *   - channel counts must be multiples of the 16-byte chunk: 4 (fp32) / 8 (bf16)

@@ -77,6 +77,17 @@ template <> __device__ __forceinline__ void frag_from_acc<bf16>(Frag<bf16>& f, c
 template <> __device__ __forceinline__ void frag_from_acc<float>(Frag<float>& f, const f32x4& a, const f32x4& b) {
   f.lo = a; f.hi = b;
 }
+// the same three for any fragment type (overloads; FragSplit = fp32 values as bf16 hi + lo, common.hpp)
+__device__ __forceinline__ void frag_from_global_x(Frag<bf16>& f, const bf16* p, bool valid) { frag_from_global<bf16>(f, p, valid); }
+__device__ __forceinline__ void frag_from_global_x(Frag<float>& f, const float* p, bool valid) { frag_from_global<float>(f, p, valid); }
+__device__ __forceinline__ void frag_from_global_x(FragSplit& f, const float* p, bool valid) {
+  Frag<float> t;
+  frag_from_global<float>(t, p, valid);
+  f.from_f32(t.lo, t.hi);
+}
+__device__ __forceinline__ void frag_from_acc_x(Frag<bf16>& f, const f32x4& a, const f32x4& b) { frag_from_acc<bf16>(f, a, b); }
+__device__ __forceinline__ void frag_from_acc_x(Frag<float>& f, const f32x4& a, const f32x4& b) { frag_from_acc<float>(f, a, b); }
+__device__ __forceinline__ void frag_from_acc_x(FragSplit& f, const f32x4& a, const f32x4& b) { f.from_f32(a, b); }
 
 template <typename T, int D> struct AttnGeom {
   static constexpr int EPV = Tr<T>::EPV, KSTEPS = Tr<T>::KSTEPS;
@@ -237,9 +248,10 @@ __device__ __forceinline__ int perm_row(int kt, int r) { return (kt >> 1) * 32 +
 // store re-reads it (same lane, L2-warm) and adds the self part -- so no second accumulator set lives across the
 // long self loop (48 registers at d = 96: one more resident wave per SIMD).  Without an out_cross buffer the sum
 // is kept in registers.
-template <typename T, int D, int QT, bool OCM>
+template <typename T, int D, int QT, bool OCM, bool SPLIT = false>
 __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
   using G = AttnGeom<T, D>;
+  using F = typename FragOf<T, SPLIT>::type;   // SPLIT (float only): both matmuls as three bf16 MFMAs on hi / lo halves
   constexpr int KSTEPS = G::KSTEPS, DS = G::DS, DT = G::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
@@ -258,12 +270,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
   const int q0 = bx * (64 * QT) + wave * (16 * QT);
 
   const T* Q = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * D;
-  Frag<T> qf[QT][DS];
+  F qf[QT][DS];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int qi = q0 + qt * 16 + l16;
 #pragma unroll
-    for (int ks = 0; ks < DS; ++ks) frag_from_global<T>(qf[qt][ks], Q + (size_t)qi * p.q_rs + ks * 32 + quad * 8, qi < p.L);
+    for (int ks = 0; ks < DS; ++ks) frag_from_global_x(qf[qt][ks], Q + (size_t)qi * p.q_rs + ks * 32 + quad * 8, qi < p.L);
   }
 
   f32x4 res[OCM ? 1 : QT][OCM ? 1 : DT];
@@ -327,10 +339,10 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
       f32x4 s[QT][4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        Frag<T> kf[DS];
+        F kf[DS];
         const int row = perm_row(kt, l16);
 #pragma unroll
-        for (int ks = 0; ks < DS; ++ks) load_frag<T>(kf[ks], Ks + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
+        for (int ks = 0; ks < DS; ++ks) load_frag_x(kf[ks], Ks + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
           s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
             for (int qt = 0; qt < QT; ++qt) s[qt][kt][i] = ok ? s[qt][kt][i] : -3.0e38f;
           }
       }
-      Frag<T> pf[QT][2];
+      F pf[QT][2];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         float mx = -3.0e38f;
@@ -379,16 +391,16 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         l_run[qt] = l_run[qt] * alpha + ls;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
-        frag_from_acc<T>(pf[qt][0], s[qt][0], s[qt][1]);
-        frag_from_acc<T>(pf[qt][1], s[qt][2], s[qt][3]);
+        frag_from_acc_x(pf[qt][0], s[qt][0], s[qt][1]);
+        frag_from_acc_x(pf[qt][1], s[qt][2], s[qt][3]);
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          Frag<T> vf;
+          F vf;
           if constexpr (PF) troff.read(vf, Vs, dt, hh);
-          else load_frag<T>(vf, Vs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
+          else load_frag_x(vf, Vs + (hh / KSTEPS) * (D * 128), dt * 16 + l16, hh % KSTEPS, quad);
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) mma16(o[qt][dt], vf, pf[qt][hh]);
         }
@@ -1213,16 +1225,16 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
 
 using namespace mdm;
 
-template <typename T, int D>
+template <typename T, int D, bool SPLIT = false>
 static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   using G = AttnGeom<T, D>;
   constexpr int smem = sizeof(T) == 2 ? 4 * G::NAT_BYTES : G::NAT_BYTES + (G::NAT_BYTES > G::TR_BYTES ? G::NAT_BYTES : G::TR_BYTES);
-  ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, true>, smem);
-  ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, false>, smem);
+  ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, true, SPLIT>, smem);
+  ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, false, SPLIT>, smem);
   const bool ocm = !a.kc || a.out_cross;   // nothing to keep, or a buffer to keep it in
   dim3 grid((a.L + 127) / 128, a.B * a.H);   // 32 queries per wave: every K / V fragment feeds two MFMAs
-  if (ocm) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, true>), grid, dim3(256), smem, st, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, false>), grid, dim3(256), smem, st, a);
+  if (ocm) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, true, SPLIT>), grid, dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, false, SPLIT>), grid, dim3(256), smem, st, a);
   MDM_LAUNCH_STATUS();
 }
 
@@ -1278,7 +1290,9 @@ extern "C" int mdm_attn_fwd(const void* qkv, const void* kvc, const float* mask,
                             float* lse_self, float* lse_cross, int B, int L, int S, int H, int d, int dtype,
                             void* stream) {
   MDM_CHECK_ARG(qkv && out);
-  MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
+  MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16 || dtype == DT_F32_SPLIT);
+  const bool split_products = dtype == DT_F32_SPLIT;   // fp32 tensors, both matmuls as bf16x3 products
+  if (split_products) dtype = DT_F32;
   MDM_CHECK_ARG(B > 0 && L > 0 && H > 0);
   MDM_CHECK_ARG(!kvc || S > 0);
   const int C = H * d;
@@ -1292,7 +1306,8 @@ extern "C" int mdm_attn_fwd(const void* qkv, const void* kvc, const float* mask,
   a.B = B; a.H = H; a.L = L; a.S = S; a.scale = 1.0f / sqrtf((float)d);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define MDM_ATTN_FWD(DD)                                                                        \
-  case DD: return dtype == DT_F32 ? attn_fwd_launch<float, DD>(a, st) : attn_fwd_launch<bf16, DD>(a, st);
+  case DD: return split_products ? attn_fwd_launch<float, DD, true>(a, st)                       \
+                                 : dtype == DT_F32 ? attn_fwd_launch<float, DD>(a, st) : attn_fwd_launch<bf16, DD>(a, st);
   switch (d) {
     MDM_ATTN_FWD(32) MDM_ATTN_FWD(64) MDM_ATTN_FWD(96) MDM_ATTN_FWD(128)
     default: MDM_CHECK_ARG(!"unsupported head dim");

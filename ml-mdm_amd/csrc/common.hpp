@@ -21,7 +21,10 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-enum { DT_F32 = 0, DT_BF16 = 1 };
+// DT_F32_SPLIT: fp32 tensors and accumulators, the products formed as three bf16 MFMAs (x = hi + lo, both bf16:
+// x*y ~ hi*hi' + hi*lo' + lo*hi') -- the arithmetic of the "fp32 at a third of the bf16 rate" sampling mode.  Accepted
+// where a kernel has the path (mdm_conv_fwd*, mdm_attn_fwd); everything else takes DT_F32 for the same tensors.
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F32_SPLIT = 2 };
 
 template <typename T> struct Tr;
 template <> struct Tr<float> {
@@ -95,6 +98,32 @@ template <> struct Frag<float> {
   }
 };
 
+// fp32 operand fragment held as two bf16 fragments, hi = bf16(x), lo = bf16(x - hi): |x - hi - lo| <= 2^-17 |x|, so the
+// three products hi*hi' + hi*lo' + lo*hi' carry x*y to ~2^-16 relative -- fp32-accumulated, 3 x v_mfma_f32_16x16x32_bf16
+// (48 cycles) for what the exact path does in 8 x v_mfma_f32_16x16x4_f32 (256 cycles).  Same lane ownership as
+// Frag<float> (row / column l & 15, reduction slots (l >> 4) * 8 + j), so it drops into the fp32 kernels' loops.
+struct FragSplit {
+  bf16x8 hi, lo;
+  __device__ __forceinline__ void from_f32(const f32x4& a, const f32x4& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16 h0 = (bf16)a[j], h1 = (bf16)b[j];
+      hi[j] = h0; hi[4 + j] = h1;
+      lo[j] = (bf16)(a[j] - (float)h0); lo[4 + j] = (bf16)(b[j] - (float)h1);
+    }
+  }
+  __device__ __forceinline__ void load_lds(const char* p0, const char* p1) {
+    from_f32(*reinterpret_cast<const f32x4*>(p0), *reinterpret_cast<const f32x4*>(p1));
+  }
+};
+template <typename T, bool SPLIT> struct FragOf { using type = Frag<T>; };
+template <> struct FragOf<float, true> { using type = FragSplit; };
+
+__device__ __forceinline__ void mma16(f32x4& acc, const FragSplit& a, const FragSplit& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, acc, 0, 0, 0);   // small terms first
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
 __device__ __forceinline__ void mma16(f32x4& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
 }
@@ -121,6 +150,13 @@ __device__ __forceinline__ void load_frag<bf16>(Frag<bf16>& f, const char* tile,
 }
 template <>
 __device__ __forceinline__ void load_frag<float>(Frag<float>& f, const char* tile, int row, int /*ks*/, int quad) {
+  f.load_lds(tile + lds_chunk_off(row, 2 * quad), tile + lds_chunk_off(row, 2 * quad + 1));
+}
+
+// the same reads for any fragment type (overloads: the fp32 kernels pick Frag<float> or FragSplit by template flag)
+__device__ __forceinline__ void load_frag_x(Frag<bf16>& f, const char* tile, int row, int ks, int quad) { load_frag<bf16>(f, tile, row, ks, quad); }
+__device__ __forceinline__ void load_frag_x(Frag<float>& f, const char* tile, int row, int ks, int quad) { load_frag<float>(f, tile, row, ks, quad); }
+__device__ __forceinline__ void load_frag_x(FragSplit& f, const char* tile, int row, int /*ks*/, int quad) {
   f.load_lds(tile + lds_chunk_off(row, 2 * quad), tile + lds_chunk_off(row, 2 * quad + 1));
 }
 

@@ -319,7 +319,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
 }
 
 // Double-buffered: the next tile's LDS-DMA overlaps this tile's MFMAs; __syncthreads() drains it (vmcnt(0)).
-template <typename T, int BM, int BN, int WM, int WN, int MODE>
+// SPLIT (float only): the products as three bf16 MFMAs on hi / lo halves of the fp32 operands (common.hpp FragSplit)
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(ConvArgs p) {
   constexpr int NSTAGE = 2;
   constexpr int EPV = Tr<T>::EPV, BK = Tr<T>::BK, KSTEPS = Tr<T>::KSTEPS;
@@ -432,9 +433,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(ConvArgs p) 
     const char* As = (cur);                                                                               \
     const char* Bs = (cur) + A_BYTES;                                                                     \
     _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                               \
-      Frag<T> af[MT], bfr[NT];                                                                            \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i) load_frag<T>(af[i], As, wm * TM + i * 16 + l16, ks, quad);   \
-      _Pragma("unroll") for (int j = 0; j < NT; ++j) load_frag<T>(bfr[j], Bs, wn * TN + j * 16 + l16, ks, quad);  \
+      typename FragOf<T, SPLIT>::type af[MT], bfr[NT];                                                    \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) load_frag_x(af[i], As, wm * TM + i * 16 + l16, ks, quad);    \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) load_frag_x(bfr[j], Bs, wn * TN + j * 16 + l16, ks, quad);   \
       _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                      \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);                   \
     }                                                                                                     \
@@ -1984,14 +1985,14 @@ __global__ __launch_bounds__(256) void upconv_bfold_kernel(const float* __restri
 static thread_local char g_last_gemm[96] = "";
 extern "C" const char* mdm_last_gemm_kernel(void) { return g_last_gemm; }
 #define MDM_NOTE_KERNEL(...) snprintf(g_last_gemm, sizeof(g_last_gemm), __VA_ARGS__)
-template <typename T, int BM, int BN, int WM, int WN, int MODE>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool SPLIT = false>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
-  auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, MODE>;
+  auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, MODE, SPLIT>;
   ensure_dynamic_lds(kern, smem);
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), smem, st, a);
-  MDM_NOTE_KERNEL("conv_gemm_kernel<%s, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : "float", BM, BN, WM, WN, MODE);
+  MDM_NOTE_KERNEL("conv_gemm_kernel<%s, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : (SPLIT ? "float (bf16x3)" : "float"), BM, BN, WM, WN, MODE);
   MDM_LAUNCH_STATUS();
 }
 
@@ -2357,10 +2358,10 @@ static int launch_conv_x_any(const ConvArgs& a, hipStream_t st) {
   return launch_conv_x<MODE, 0, false>(a, st);
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool SPLIT = false>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
-  if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE>(a, st);
-  if (a.Cout <= 64) return launch_conv_cfg<T, 128, 64, 2, 2, MODE>(a, st);
+  if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE, SPLIT>(a, st);
+  if (a.Cout <= 64) return launch_conv_cfg<T, 128, 64, 2, 2, MODE, SPLIT>(a, st);
   const int code = conv_tile_code(a.M, a.Cout, sizeof(T) == 2 ? DT_BF16 : DT_F32);
   if constexpr (sizeof(T) == 2) {
     if constexpr (MODE != MODE_3x3_T2) {
@@ -2374,14 +2375,14 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
     // problems the buffer-addressed loader cannot express (ragged K, transposed stride-2 gradient, > 2 GiB operands)
     if (code != 128128) return launch_conv_cfg<T, 256, 256, 2, 4, MODE>(a, st);
   }
-  return launch_conv_cfg<T, 128, 128, 2, 2, MODE>(a, st);
+  return launch_conv_cfg<T, 128, 128, 2, 2, MODE, SPLIT>(a, st);
 }
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 static int launch_conv_t(const ConvArgs& a, int ks, int transposed, hipStream_t st) {
-  if (ks == 1) return launch_conv_mode<T, MODE_1x1>(a, st);
-  if (transposed) return launch_conv_mode<T, MODE_3x3_T2>(a, st);
-  return launch_conv_mode<T, MODE_3x3>(a, st);
+  if (ks == 1) return launch_conv_mode<T, MODE_1x1, SPLIT>(a, st);
+  if (transposed) return launch_conv_mode<T, MODE_3x3_T2, SPLIT>(a, st);
+  return launch_conv_mode<T, MODE_3x3, SPLIT>(a, st);
 }
 
 // ws / ws_bytes: optional fp32 workspace sized by mdm_conv_fwd_plan; with it, problems too small to fill the chip with
@@ -2392,7 +2393,9 @@ extern "C" int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float*
                                float* ws, size_t ws_bytes, void* stream) {
   MDM_CHECK_ARG(x && w_packed && y);
   MDM_CHECK_ARG(ksize == 1 || ksize == 3);
-  MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
+  MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16 || dtype == DT_F32_SPLIT);
+  const bool split_products = dtype == DT_F32_SPLIT;   // fp32 tensors, bf16x3 products (include/mdm_hip.h MDM_DT_F32_SPLIT)
+  if (split_products) dtype = DT_F32;
   MDM_CHECK_ARG(act >= 0 && act <= 2);
   MDM_CHECK_ARG(act != 2 || aux);
   const int epv = dtype == DT_F32 ? 4 : 8;
@@ -2418,6 +2421,7 @@ extern "C" int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float*
       if (ksize == 3 && conv_bl_ok<bf16, MODE_3x3>(a)) return launch_conv_bl_splitk<MODE_3x3>(a, sp, ws, st);
     }
   }
+  if (split_products) return launch_conv_t<float, true>(a, ksize, transposed, st);
   return dtype == DT_F32 ? launch_conv_t<float>(a, ksize, transposed, st) : launch_conv_t<bf16>(a, ksize, transposed, st);
 }
 

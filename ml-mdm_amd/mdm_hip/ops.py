@@ -16,7 +16,35 @@ import torch
 
 from . import _lib
 
-F32, BF16 = 0, 1
+F32, BF16, F32_SPLIT = 0, 1, 2
+
+# fp32 tensors, products as three bf16 MFMAs on bf16 hi + lo halves (include/mdm_hip.h MDM_F32_SPLIT): the arithmetic of
+# sampling at the reference's precision (it samples in fp32, diffusion.py:181-197) at about a third of the bf16 rate.  Only
+# the forward matmul-class launches have the path (convolutions / linears, attention); training in fp32 stays exact.
+_fp32_split = False
+
+
+class fp32_split:
+    """``with ops.fp32_split():`` (or ``ops.fp32_split(True)`` / ``(False)`` as a switch) -- fp32 forward passes inside run
+    their convolutions, linears and attention as bf16x3 products.  No effect on bf16 tensors or on backward kernels."""
+
+    def __init__(self, enabled: bool = True):
+        global _fp32_split
+        self._prev = _fp32_split
+        _fp32_split = bool(enabled)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        global _fp32_split
+        _fp32_split = self._prev
+
+
+def _dt_mm(t: torch.Tensor) -> int:
+    """dtype code of a forward matmul-class launch"""
+    d = _dt(t)
+    return F32_SPLIT if (d == F32 and _fp32_split) else d
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -538,7 +566,7 @@ def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, 
     def go():
         _lib.check(
             _lib.lib().mdm_conv_fwd_ws(_p(x), _p(w), _p(bias), _p(res), _p(aux), _p(y), _p(ypre), N, H, W, Cin, Ho, Wo, Cout,
-                                       ks, stride, transposed, act, kblk, _dt(x), _p(ws), wsb, _stream()),
+                                       ks, stride, transposed, act, kblk, _dt_mm(x), _p(ws), wsb, _stream()),
             "mdm_conv_fwd",
         )
 
@@ -1288,7 +1316,7 @@ class AttentionFn(torch.autograd.Function):
         lse_c = torch.empty((B, heads, L), dtype=torch.float32, device=qkv.device) if (keep and kvc is not None) else None
         oc = torch.empty_like(out) if kvc is not None else None   # also the kernel's staging buffer for the cross part
         _prof_wrap("attn_fwd_kernel<d=%d> L=%d" % (d, L), 4.0 * B * heads * L * (L + S) * d, lambda: _lib.check(
-            _lib.lib().mdm_attn_fwd(_p(qkv), _p(kvc), _p(m32), _p(out), _p(oc), _p(lse_s), _p(lse_c), B, L, S, heads, d, _dt(qkv), _stream()),
+            _lib.lib().mdm_attn_fwd(_p(qkv), _p(kvc), _p(m32), _p(out), _p(oc), _p(lse_s), _p(lse_c), B, L, S, heads, d, _dt_mm(qkv), _stream()),
             "mdm_attn_fwd",
         ), kind="attn")
         ctx.save_for_backward(qkv, kvc, m32, out, oc, lse_s, lse_c)

@@ -107,6 +107,60 @@ def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
     assert relerr(nchw(rd.grad), res.grad) < tol
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks,stride", [(2, 16, 16, 256, 320, 3, 1), (3, 24, 20, 136, 200, 1, 1), (2, 18, 22, 64, 40, 3, 2),
+                                                     (2, 9, 7, 32, 24, 3, 1)])
+def test_conv_fp32_split_products(N, H, W, Cin, Cout, ks, stride):
+    """MDM_F32_SPLIT (ops.fp32_split): fp32 tensors, every product as three bf16 MFMAs on bf16 hi + lo halves (common.hpp
+    FragSplit) -- the sampling-at-reference-precision mode.  Against the torch fp32 convolution: an order of magnitude
+    looser than the exact-fp32 MFMA path (2e-5), three orders tighter than bf16 (3e-2)."""
+    from mdm_hip import _lib, ops
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, Cout, (H - 1) // stride + 1, (W - 1) // stride + 1, generator=g)
+    y_ref = F.conv2d(x, w, b, stride=stride, padding=(ks - 1) // 2) + res
+    with torch.no_grad(), ops.fp32_split():
+        y = ops.conv(nhwc(x, torch.float32), w.to(dev()), b.to(dev()), residual=nhwc(res, torch.float32), stride=stride)
+        torch.cuda.synchronize()
+        assert "bf16x3" in _lib.lib().mdm_last_gemm_kernel().decode()
+    err = relerr(nchw(y), y_ref)
+    assert err < 2e-4, err
+    with torch.no_grad():   # and the switch is off again: the exact path
+        y2 = ops.conv(nhwc(x, torch.float32), w.to(dev()), b.to(dev()), residual=nhwc(res, torch.float32), stride=stride)
+        assert "bf16x3" not in _lib.lib().mdm_last_gemm_kernel().decode()
+    assert relerr(nchw(y2), y_ref) < TOL[torch.float32]
+
+
+@pytest.mark.parametrize("B,L,S,H,d,masked", [(2, 256, 32, 4, 96, True), (1, 1024, 32, 2, 64, False), (3, 64, 0, 2, 32, False)])
+def test_attention_fp32_split_products(B, L, S, H, d, masked):
+    """the attention forward in the same mode: Q K^T and P V as bf16x3 products, fp32 softmax"""
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(8)
+    C = H * d
+    qkv = torch.randn(B, L, 3 * C, generator=g) * 1.2
+    kvc = torch.randn(B, S, 2 * C, generator=g) if S else None
+    mask = (torch.rand(B, S, generator=g) > 0.3).float() if (S and masked) else None
+    if mask is not None:
+        mask[:, 0] = 1.0
+    qh, kh, vh = [t.reshape(B, L, H, d).transpose(1, 2) for t in qkv.split(C, -1)]
+    sc = 1.0 / math.sqrt(d)
+    ref = torch.softmax(qh @ kh.transpose(-1, -2) * sc, -1) @ vh
+    if S:
+        kc, vc = [t.reshape(B, S, H, d).transpose(1, 2) for t in kvc.split(C, -1)]
+        sx = qh @ kc.transpose(-1, -2) * sc
+        if mask is not None:
+            sx = sx.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+        ref = ref + torch.softmax(sx, -1) @ vc
+    ref = ref.transpose(1, 2).reshape(B, L, C)
+    with torch.no_grad(), ops.fp32_split():
+        out = ops.attention(qkv.to(dev()), kvc.to(dev()) if S else None, mask.to(dev()) if mask is not None else None, H)
+    err = relerr(out.float().cpu(), ref)
+    assert err < 2e-4, err
+
+
 @pytest.mark.parametrize("act,with_res", [(0, False), (0, True), (1, False), (2, False)])
 @pytest.mark.parametrize(
     "N,H,W,Cin,Cout,ks",
