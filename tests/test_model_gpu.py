@@ -548,7 +548,7 @@ def test_long_horizon_sampling_matches_reference(name, tmp_path):
             PC.check_summary(out.float(), gold["out"], "long." + name, 1e-3)
         if mode == "fp32x3":
             # fp32 tensors, bf16x3 products (MDM_F32_SPLIT): the mode the fp32 sampling bench legs time -- same gate
-            PC.check_summary(out.float(), gold["out"], "long.x3." + name, 1e-3)
+            PC.check_summary(out.float(), gold["out"], "long." + name, 1e-3)
         st = max(1, out.shape[-1] // 64)
         errs[mode] = O.rel_l2(out.float()[..., ::st, ::st], gold["out"]["sub"])
     pipe.sampler.device_rng = None
