@@ -32,8 +32,9 @@
 /* Bumped whenever an exported signature changes; mdm_abi_version() returns the value the library was built with.
  *   1  round 1
  *   2  mdm_sumsq / mdm_adamw_ema_step gained parameters, mdm_gn_bwd a third accumulate mode (round 2)
+ *   4  MDM_F32_SPLIT dtype code (mdm_conv_fwd*, mdm_attn_fwd), mdm_dropout (round 4)
  *   3  round 3 */
-#define MDM_HIP_ABI_VERSION 3
+#define MDM_HIP_ABI_VERSION 4
 
 #ifdef __cplusplus
 extern "C" {
@@ -291,6 +292,12 @@ int mdm_sample_std_fwd(const float* x, float* y, float* stats, float* ws, int N,
 int mdm_sample_std_bwd(const float* dy, const float* x, const float* stats, float* dx, float* ws, int N, size_t chw,
                        void* stream);
 int mdm_input_stage(const void* u8_nhwc, float* out_nchw, int B, int H, int W, void* stream);
+/* mdm_dropout (ABI 4; nn.Dropout of a ResNet block, models/unet.py:208,234): y[i] = keep(i) ? x[i] / (1 - p) : 0 over n
+ * elements (n % 8 == 0), keep(i) = Philox4x32-10 word of element i under (seed, offset) >= p * 2^32.  The mask is a pure
+ * function of (seed, offset, i): the backward pass calls the same entry on dy with the same two integers.  One call
+ * consumes n / 4 counter blocks (the caller advances its offset by that much). */
+int mdm_dropout(const void* x, void* y, size_t n, float p, unsigned long long seed, unsigned long long offset, int dtype,
+                void* stream);
 
 #ifdef __cplusplus
 }

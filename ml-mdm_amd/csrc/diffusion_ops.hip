@@ -485,3 +485,64 @@ extern "C" int mdm_input_stage(const void* u8_nhwc, float* out_nchw, int B, int 
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint8_t*>(u8_nhwc), out_nchw, B, hw);
   MDM_LAUNCH_STATUS();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Dropout (reference models/unet.py:208,234: nn.Dropout between norm2 + SiLU and conv2 of a ResNet block).
+// y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) = (Philox word of element i) >= p * 2^32: a pure function of
+// (seed, offset, i), so backward regenerates the same mask from the two integers instead of storing it.  The same
+// launch serves both directions (dx = dy masked and scaled the same way).  8 elements per thread = two Philox blocks.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n8, unsigned thresh,
+                                                      float scale, unsigned long long seed, unsigned long long offset) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    float v[8];
+    if constexpr (sizeof(T) == 2) {
+      Chunk<T> c;
+      c.load(x + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = c.v[e];
+    } else {
+      Chunk<T> c0, c1;
+      c0.load(x + i * 8); c1.load(x + i * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = c0.v[e]; v[4 + e] = c1.v[e]; }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned long long ctr = offset + 2 * i + h;
+      uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x44524f50u /* "DROP" */, 0u};
+      philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * h + e] = c[e] >= thresh ? v[4 * h + e] * scale : 0.f;
+    }
+    if constexpr (sizeof(T) == 2) {
+      Chunk<T> c;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c.v[e] = v[e];
+      c.store(y + i * 8);
+    } else {
+      Chunk<T> c0, c1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { c0.v[e] = v[e]; c1.v[e] = v[4 + e]; }
+      c0.store(y + i * 8); c1.store(y + i * 8 + 4);
+    }
+  }
+}
+
+extern "C" int mdm_dropout(const void* x, void* y, size_t n, float p, unsigned long long seed, unsigned long long offset,
+                           int dtype, void* stream) {
+  MDM_CHECK_ARG(x && y && n % 8 == 0 && p >= 0.f && p < 1.f);
+  MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
+  if (n == 0) return 0;
+  const size_t n8 = n / 8;
+  const double t = (double)p * 4294967296.0;
+  const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  const float scale = 1.f / (1.f - p);
+  const unsigned blocks = (unsigned)((n8 + 255) / 256 > 8192 ? 8192 : (n8 + 255) / 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == DT_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, n8, thresh, scale, seed, offset);
+  else hipLaunchKernelGGL(dropout_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n8, thresh, scale, seed, offset);
+  MDM_LAUNCH_STATUS();
+}

@@ -1779,3 +1779,46 @@ def adamw_ema_step(p, g, m, v, ema, gnorm_sq, lr, beta1, beta2, eps, weight_deca
         "mdm_adamw_ema_step",
     ), kind="hbm")
     invalidate_packed_weights()
+
+
+# --------------------------------------------------------------------------------------
+# dropout (nn.Dropout of a ResNet block, reference models/unet.py:208,234)
+# --------------------------------------------------------------------------------------
+_dropout_rng = [None, 0]   # [seed, next Philox counter block]; seeded from torch's generator on first use
+
+
+def seed_dropout(seed: int):
+    """restart the dropout mask stream (default: torch.initial_seed() at the first call)"""
+    _dropout_rng[0], _dropout_rng[1] = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        _require_gpu(x)
+        x = _c(x)
+        if _dropout_rng[0] is None:
+            seed_dropout(torch.initial_seed())
+        seed, off = _dropout_rng
+        _dropout_rng[1] = off + (x.numel() + 3) // 4
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().mdm_dropout(_p(x), _p(y), x.numel(), float(p), seed, off, _dt(x), _stream()), "mdm_dropout")
+        ctx.p, ctx.seed, ctx.off = float(p), seed, off
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        _lib.check(_lib.lib().mdm_dropout(_p(dy), _p(dx), dy.numel(), ctx.p, ctx.seed, ctx.off, _dt(dy), _stream()), "mdm_dropout")
+        return dx, None
+
+
+def dropout(x, p: float, training: bool = True):
+    """``F.dropout(x, p, training)`` with a counter-based mask (Philox, regenerated in backward instead of stored).  The
+    mask differs from torch's for the same seed -- as between any two generators -- the distribution is the same."""
+    if not training or p <= 0.0:
+        return x
+    if x.numel() % 8 != 0:
+        raise _lib.MdmHipError("dropout: the element count must be a multiple of 8")
+    return DropoutFn.apply(x, p)

@@ -128,8 +128,6 @@ class ResNet(nn.Module):
         ``list[index]`` holds this very x as a skip activation (reference unet.py:883-897); it is replaced by a second
         pass-through output of norm1, so that in backward the skip connection's gradient reaches x inside the
         GroupNorm kernel instead of through an accumulation kernel of the autograd engine."""
-        if self.config.dropout > 0 and self.training:
-            raise NotImplementedError("dropout > 0 is not implemented on the HIP path")
         g = self.config.num_groups_norm
         if tap is not None and x.requires_grad and tap[0][tap[1]] is x and _SKIP_TAP:
             h, x, tap[0][tap[1]] = ops.group_norm(x, self.norm1.weight, self.norm1.bias, g, self.norm1.eps, silu=True, passthrough=2)
@@ -145,6 +143,8 @@ class ResNet(nn.Module):
         if film.shape[0] != h.shape[0]:
             raise NotImplementedError("time-embedding batch repeat (temporal mode) is not implemented")
         h = ops.group_norm(h, self.norm2.weight, self.norm2.bias, g, self.norm2.eps, film=film, silu=True)
+        if self.config.dropout > 0 and self.training:   # reference :234 (nn.Dropout; the shipped configs use 0.0)
+            h = ops.dropout(h, self.config.dropout, True)
         shortcut = x
         if self.config.output_channels != self.config.num_channels:
             shortcut = ops.conv(x, self.conv3.weight, self.conv3.bias)

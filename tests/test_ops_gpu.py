@@ -908,3 +908,54 @@ def test_small_problem_split_k_matches_unsplit(case):
     assert sum(1 for v in seen if v > 1) >= (2 if case == "ffn" else 1), seen   # the launches this case is about were split
     for a, b_ in zip(split, plain):
         assert relerr(a, b_) < 8e-3     # bf16 outputs: an fp32 sum in another order moves a few results by one ulp (2^-8)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropout_counter_based_mask(dtype):
+    """ops.dropout (nn.Dropout of a ResNet block, models/unet.py:208,234): kept elements are scaled by 1 / (1 - p), the
+    rest are zero, the keep rate matches p, the mask is a pure function of (seed, counter) -- same seed, same mask; the
+    next call draws a fresh one -- and backward applies the mask of ITS forward call"""
+    from mdm_hip import ops
+
+    p = 0.3
+    x = (torch.randn(4, 16, 16, 64) + 3.0).to(dtype).to(dev()).requires_grad_()
+    ops.seed_dropout(1234)
+    y1 = ops.dropout(x, p, True)
+    y2 = ops.dropout(x, p, True)
+    kept = y1 != 0
+    rate = float(kept.float().mean())
+    assert abs(rate - (1 - p)) < 0.02, rate
+    assert torch.allclose(y1[kept].float(), (x.detach()[kept].float() / (1 - p)).to(dtype).float(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-6)
+    assert not torch.equal(y1 != 0, y2 != 0)                    # the stream advanced
+    ops.seed_dropout(1234)
+    assert torch.equal(ops.dropout(x, p, True), y1)              # replayable
+    gy = torch.ones_like(y2)
+    (gx,) = torch.autograd.grad(y2, x, gy)
+    assert torch.equal(gx != 0, y2 != 0) and abs(float(gx[gx != 0].float().mean()) - 1 / (1 - p)) < 1e-2
+    assert ops.dropout(x, p, False) is x and ops.dropout(x, 0.0, True) is x
+
+
+def test_resnet_block_with_dropout_trains():
+    """UNet config with dropout > 0 (reference ResNetConfig.dropout): forward + backward run in training mode, eval mode
+    is deterministic and equals the dropout-free model"""
+    import parity_cases as PC
+    from mdm_hip import ops
+
+    model, _, _ = PC.build_module("mini_unet")
+    model = model.to(dev())
+    for m in model.modules():
+        if hasattr(m, "config") and hasattr(m.config, "dropout"):
+            m.config.dropout = 0.25
+    inp = PC.inputs("mini_unet")
+    args = (inp["x"].to(dev()), inp["times"].to(dev()), inp["cond"].to(dev()), inp["mask"].to(dev()))
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model(*args), model(*args)
+    assert torch.equal(e1, e2)
+    model.train()
+    ops.seed_dropout(7)
+    t1 = model(*args)
+    t2 = model(*args)
+    assert not torch.equal(t1, t2) and bool(torch.isfinite(t1).all())
+    t1.square().mean().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
