@@ -18,7 +18,7 @@ int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype);
  *   0  conv_gemm_x_kernel: bit 0 = its LDS-DMA fetches nothing, bit 1 = its barriers do not wait for the DMA (timing only)
  *   1  epilogues skip their global stores (what the store phase costs)
  *   2  force the forward tile of conv_gemm_bl_kernel (128128 / 256192 / 256256)
- *   3  conv_gemm_x_kernel: 0 = by the host rule, 1 = never, 2 = whenever the problem allows
+ *   3  conv_gemm_x_kernel (csrc/gemm_x.hpp): 0 / 1 = never (the product: it does not pay inside the train step), 2 = whenever the problem allows
  *   4  conv_gemm_x_kernel tile order: 0 = row-major, 1 = super-tiles (default)
  *   6  tile-fill percentage below which a forward GEMM may split its reduction (default 80; 25 = the sampling-only rule)
  *   7  1 = the narrow 3x3 convolutions of the nested models go back to the implicit-GEMM kernel (no conv3x3_direct_kernel) */

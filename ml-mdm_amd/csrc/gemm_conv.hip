@@ -580,6 +580,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
       const int n = n0 + lrow + RPP * j;                                                                    \
       b_voff[j] = n < p.Cout ? (unsigned)n * p.K * 2u + lchunk * 16u : INVALID;                             \
     }                                                                                                       \
+    if (g_knobs[0] & 1) {   /* development knob 0: the LDS-DMA fetches nothing (what the k-loop costs without memory) */ \
+      _Pragma("unroll") for (int j = 0; j < AJ; ++j) a_voff[j] = INVALID;                                   \
+      _Pragma("unroll") for (int j = 0; j < BJ; ++j) b_voff[j] = INVALID;                                   \
+    }                                                                                                       \
   }
   const unsigned a_bytes = (unsigned)p.N * p.H * p.W * p.Cin * 2u + bias;
   const unsigned b_bytes = (unsigned)p.Cout * p.K * 2u;
@@ -2307,7 +2311,7 @@ static int launch_conv_direct_any(const ConvArgs& a, hipStream_t st) {
 }
 
 // ---- conv_gemm_x_kernel (gemm_x.hpp): continuous k-tile stream, the epilogue of tile n under the MFMAs of tile n+1 ----
-static int g_force_x = 0;   // development knob 3 (mdm_dev_set_knob): 0 = rule below, 1 = never, 2 = whenever the kernel can
+static int g_force_x = 0;   // development knob 3 (mdm_dev_set_knob): 0 / 1 = never (the product), 2 = whenever the kernel can
 static int g_x_order = 1;   // development knob 4: 0 = row-major tile order, 1 = super-tiles (below)
 template <int MODE, int ACT, bool RES>
 static int launch_conv_x(const ConvArgs& a0, hipStream_t st) {
@@ -2338,20 +2342,18 @@ static bool conv_x_can(const ConvArgs& a) {
   if (a.act == 2 ? (a.res != nullptr || !a.aux) : (a.act == 1 && (a.res != nullptr || !a.ypre))) return false;
   return (size_t)a.M * a.Cout * 2 < 0x7F000000u;
 }
-// ... and is it the better choice?  Its strength is the hidden per-tile tail, its price a 256 x 128 tile: 1.5x the
-// LDS-DMA bytes per FLOP of 256 x 256, and the k-loop of either kernel ends up bound by what a CU's vector-memory path
-// moves (~50 GB/s per CU measured, profiles/r04_gemm_x8_probe.txt).  Measured per layer shape of the U-Net, variants
-// interleaved: it wins where the tail is a large part of a tile -- 1x1 convolutions (K = 512 ... 768) with wide outputs
-// (768 -> 3072 with either activation +9 ... 15 %, 512 -> 1536 +22 %, 512 -> 2048 x gelu'(aux) +16 %) -- ties at
-// 768 -> 2304, and loses on the 3x3 convolutions (long reductions: the tail is small, the operand traffic is not), on
-// N = 768 (1.5 tiles per CU) and on K = 512 with two outputs (GELU + pre-activation: 128 KB of stores per 8 k-tiles).
+// ... and is it the better choice?  Measured (profiles/r04_gemm_x8_probe.txt, r04_gemm_probe_fresh_output_buffers.txt,
+// variants interleaved): rewriting ONE output buffer it wins 9-22 % on the wide 1x1 convolutions with short reductions
+// (768 -> 3072, 512 -> 1536, 512 -> 2048 x gelu'), but with a FRESH output buffer per launch -- what a train step does --
+// the margin shrinks to 3-6 %, the GELU + pre-activation case (two outputs) loses 20 %, and inside the 64x64 U-Net's
+// train step the two kernels are indistinguishable (95.6 vs 95.4 ms, two alternations in one call).  Why: its waits are
+// counted but vmcnt retires in order, so a store to a cold line that takes longer than two k-tile iterations to retire
+// stalls the LDS-DMA behind it, and its 256 x 128 tile moves 1.5x the LDS-DMA bytes per FLOP through a vector-memory
+// path that sustains ~50 GB/s per CU for either kernel.  So conv_gemm_bl_kernel stays the product path; this kernel is
+// kept (parity-tested through development knob 3 = 2) as the measured record of that structure.
 static bool conv_x_wanted(const ConvArgs& a, int ksize) {
-  if (g_force_x == 1) return false;
-  if (!conv_x_can(a)) return false;
-  if (g_force_x == 2) return true;
-  const long tiles = (long)(a.M / XG::BM) * (a.Cout / XG::BN);
-  if (ksize != 1 || tiles < 5L * device_cus()) return false;
-  return !(a.act == 1 && a.K < 768);
+  (void)ksize;
+  return g_force_x == 2 && conv_x_can(a);
 }
 template <int MODE>
 static int launch_conv_x_any(const ConvArgs& a, hipStream_t st) {

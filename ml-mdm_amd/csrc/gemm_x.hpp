@@ -320,8 +320,13 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_x_kernel(ConvArgs p) {
   // stage 3: the stores (issued right after a barrier, before the loader's next piece)
 #define MDX_DRAIN_STORE(DST, SL)                                                                            \
   if (do_store) {                                                                                           \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                           \
-      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(DST) + MDX_ROW_OFF(SL, q)) = dr_raw[(SL) & 1][q];  \
+    if (xknob & 4) {   /* development knob 0, bit 2: non-temporal stores */                                 \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                         \
+        __builtin_nontemporal_store(dr_raw[(SL) & 1][q], reinterpret_cast<u32x4*>(reinterpret_cast<char*>(DST) + MDX_ROW_OFF(SL, q))); \
+    } else {                                                                                                \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                         \
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(DST) + MDX_ROW_OFF(SL, q)) = dr_raw[(SL) & 1][q]; \
+    }                                                                                                       \
   }
 #define MDX_DRAIN_LOAD_OP(SL)                                                                               \
   if constexpr (OPND) {                                                                                     \

@@ -138,8 +138,8 @@ def _apply_dev_env(handle):
         handle.mdm_dev_set_knob(6, int(os.environ["MDM_HIP_SPLIT_FILL"]))
     if os.environ.get("MDM_HIP_CONV_DIRECT") == "0":
         handle.mdm_dev_set_knob(7, 1)
-    if os.environ.get("MDM_HIP_GEMM_X") in ("0", "2"):   # 0: never conv_gemm_x_kernel, 2: whenever it can
-        handle.mdm_dev_set_knob(3, 1 if os.environ["MDM_HIP_GEMM_X"] == "0" else 2)
+    if os.environ.get("MDM_HIP_GEMM_X") == "2":   # conv_gemm_x_kernel whenever the problem allows (default: never)
+        handle.mdm_dev_set_knob(3, 2)
 
 
 def check(rc: int, what: str):

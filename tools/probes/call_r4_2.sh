@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4
-timeout 600 tools/probes/gemm_probe 64 10 > gpurun_out/r4/probe5.log 2>&1
-echo "probe rc=$?" >> gpurun_out/r4/probe5.log
-cat gpurun_out/r4/probe5.log
+timeout 600 tools/probes/gemm_probe 64 10 > gpurun_out/r4/probe6.log 2>&1
+echo "probe rc=$?" >> gpurun_out/r4/probe6.log
+cat gpurun_out/r4/probe6.log

@@ -117,11 +117,18 @@ int main(int argc, char** argv) {
     if (only && !strstr(s.name, only)) continue;
     const int M = B * s.H * s.H, K = s.ks * s.ks * s.Cin;
     const size_t nx = (size_t)M * s.Cin, nw = (size_t)s.Cout * K, ny = (size_t)M * s.Cout;
+    // RING > 0 (argv[4]): every launch of the timing loops writes a different output buffer of a ring larger than the
+    // 256 MB Infinity Cache -- fresh destination lines, as inside a train step (rewriting one buffer lets the caches
+    // absorb the stores)
+    const int RING = argc > 4 ? atoi(argv[4]) : 0;
+    std::vector<bf16*> ring_y, ring_p;
     bf16 *x, *w, *y[2], *yp[2], *yr, *ypr, *res = nullptr, *aux = nullptr;
     float* bias;
     CK(hipMalloc(&x, nx * 2)); CK(hipMalloc(&w, nw * 2)); CK(hipMalloc(&bias, s.Cout * 4));
     for (int v = 0; v < 2; ++v) { CK(hipMalloc(&y[v], ny * 2)); CK(hipMalloc(&yp[v], ny * 2)); CK(hipMemset(y[v], 0x7f, ny * 2)); CK(hipMemset(yp[v], 0x7f, ny * 2)); }
     CK(hipMalloc(&yr, ny * 2)); CK(hipMalloc(&ypr, ny * 2));
+    for (int r = 0; r < RING; ++r) { bf16 *a_, *b_; CK(hipMalloc(&a_, ny * 2)); CK(hipMalloc(&b_, ny * 2)); ring_y.push_back(a_); ring_p.push_back(b_); }
+    int ring_i = 0;
     fill_bf16<<<(nx + 255) / 256, 256, 0, st>>>(x, nx, 1u, 1.f);
     fill_bf16<<<(nw + 255) / 256, 256, 0, st>>>(w, nw, 2u, 1.7f / sqrtf((float)K));
     fill_f32<<<(s.Cout + 255) / 256, 256, 0, st>>>(bias, s.Cout, 3u, 0.5f);
@@ -132,7 +139,8 @@ int main(int argc, char** argv) {
     // 2 = x, row-major tile order; 3 = x, LDS-DMA fetches nothing; 4 = x, barriers do not wait for the DMA; 5 = both;
     // 6 = x without the drain's stores
     // 7 = conv_gemm_bl_kernel with the full wait for its stores before the next tile (dev knob 5: the round-3 behaviour)
-    const int NV = 8;
+    // 8 = conv_gemm_bl_kernel whose LDS-DMA fetches nothing, 9 = the same without stores either
+    const int NV = 10;
     double us[NV] = {0};
     char kname[2][96];
     // interleaved rounds (variant order rotates; the median of the rounds is reported): a variant timed once, first, right
@@ -142,15 +150,16 @@ int main(int argc, char** argv) {
     for (int r = 0; r < ROUNDS; ++r)
       for (int vi = 0; vi < NV; ++vi) {
         const int v = (vi + r) % NV;
-        mdm_dev_set_knob(3, (v == 0 || v == 7) ? 1 : 2);
-        mdm_dev_set_knob(5, v == 7 ? 1 : 0);
-        mdm_dev_set_knob(4, v == 2 ? 0 : 1);
-        mdm_dev_set_knob(0, v == 3 ? 1 : v == 4 ? 2 : v == 5 ? 3 : 0);
-        mdm_dev_set_knob(1, v == 6 ? 1 : 0);
+        mdm_dev_set_knob(3, (v == 0 || v >= 7) ? 1 : 2);
+        mdm_dev_set_knob(4, 1);
+        mdm_dev_set_knob(0, (v == 3 || v >= 8) ? 1 : v == 4 ? 2 : v == 5 ? 3 : v == 2 ? 4 : 0);
+        mdm_dev_set_knob(1, (v == 6 || v == 9) ? 1 : 0);
         bf16* yy = v < 2 ? y[v] : yr;              // experiments write into scratch outputs (the reference rows come later)
         bf16* ypp = v < 2 ? yp[v] : ypr;
         auto run = [&]() {
-          int rc = mdm_conv_fwd(x, w, bias, res, aux, yy, s.act == 1 ? ypp : nullptr, B, s.H, s.H, s.Cin, s.H, s.H, s.Cout, s.ks, 1, 0,
+          bf16* yy_ = yy; bf16* ypp_ = ypp;
+          if (RING > 0) { yy_ = ring_y[ring_i % RING]; ypp_ = ring_p[ring_i % RING]; ++ring_i; }
+          int rc = mdm_conv_fwd(x, w, bias, res, aux, yy_, s.act == 1 ? ypp_ : nullptr, B, s.H, s.H, s.Cin, s.H, s.H, s.Cout, s.ks, 1, 0,
                                 s.act, kblk, 1, st);
           if (rc) { printf("mdm_conv_fwd rc=%d: %s\n", rc, mdm_last_error()); exit(1); }
         };
@@ -166,7 +175,7 @@ int main(int argc, char** argv) {
         tv[v].push_back(ms * 1e3 / iters);
       }
     for (int v = 0; v < NV; ++v) { std::sort(tv[v].begin(), tv[v].end()); us[v] = tv[v][ROUNDS / 2]; }
-    mdm_dev_set_knob(0, 0); mdm_dev_set_knob(1, 0); mdm_dev_set_knob(4, 1); mdm_dev_set_knob(5, 0);
+    mdm_dev_set_knob(0, 0); mdm_dev_set_knob(1, 0); mdm_dev_set_knob(4, 1);
     mdm_dev_set_knob(3, 0);
     // X vs the 8-wave kernel, every element
     unsigned long long bad[3] = {0, 0, 0};
@@ -194,12 +203,13 @@ int main(int argc, char** argv) {
     CK(hipMemcpyAsync(&badbl, d_bad, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&mrbl, d_max, 4, hipMemcpyDeviceToHost, st));
     CK(hipStreamSynchronize(st));
     const double fl = 2.0 * M * s.Cout * K;
-    printf("%-26s M=%-6d N=%-4d K=%-5d | bl %7.1f us %6.0f TF | x %7.1f us %6.0f TF | x/bl %.3f | rowmajor %7.1f | noDMA %7.1f | nowait %7.1f | both %7.1f | nostore %7.1f | bl-oldwait %7.1f | bl vs naive: bad %llu maxrel %.3g | x vs bl: bad %llu maxrel %.3g%s | vs naive: bad %llu maxrel %.3g | %s / %s\n",
-           s.name, M, s.Cout, K, us[0], fl / us[0] * 1e-6, us[1], fl / us[1] * 1e-6, us[1] / us[0], us[2], us[3], us[4], us[5], us[6], us[7], badbl, mrbl, bad[0], mr[0],
+    printf("%-26s M=%-6d N=%-4d K=%-5d | bl %7.1f us %6.0f TF | x %7.1f us %6.0f TF | x/bl %.3f | x-nt-stores %7.1f | noDMA %7.1f | nowait %7.1f | both %7.1f | nostore %7.1f | bl(again) %7.1f | bl noDMA %7.1f | bl noDMA nostore %7.1f | bl vs naive: bad %llu maxrel %.3g | x vs bl: bad %llu maxrel %.3g%s | vs naive: bad %llu maxrel %.3g | %s / %s\n",
+           s.name, M, s.Cout, K, us[0], fl / us[0] * 1e-6, us[1], fl / us[1] * 1e-6, us[1] / us[0], us[2], us[3], us[4], us[5], us[6], us[7], us[8], us[9], badbl, mrbl, bad[0], mr[0],
            s.act == 1 ? (bad[1] ? " (ypre BAD)" : " (ypre ok)") : "", bad[2], mr[2], kname[0], kname[1]);
     fflush(stdout);
     CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(bias)); CK(hipFree(yr)); CK(hipFree(ypr));
     for (int v = 0; v < 2; ++v) { CK(hipFree(y[v])); CK(hipFree(yp[v])); }
+    for (int r = 0; r < RING; ++r) { CK(hipFree(ring_y[r])); CK(hipFree(ring_p[r])); }
     if (res) CK(hipFree(res));
     if (aux) CK(hipFree(aux));
   }
