@@ -26,9 +26,6 @@ int mdm_dev_set_knob(int idx, int value);
 /* attention backward kernel choice: 0 = by shape, 1 = always the split (dQ + dK/dV) kernels, 2 = the one-block-per-head
  * kernel whenever the shape allows (tests) */
 int mdm_dev_set_attn_bwd(int mode);
-/* GroupNorm of large images: 1 (default) = the single-pass cluster kernels where they apply and pay, 0 = always the
- * two-kernel (partial + apply) path, 2 = the cluster kernels wherever they apply, however small the grid (tests) */
-int mdm_dev_set_gn_cluster(int mode);
 
 #ifdef __cplusplus
 }

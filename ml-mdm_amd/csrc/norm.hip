@@ -650,358 +650,6 @@ static int gn_fused_cb(int HW, int C, int G, int dtype, int max_ni) {
 }
 
 // ---------------------------------------------------------------------------------
-// Single-pass GroupNorm for LARGE images (the 32x32 and 64x64 levels): a CLUSTER of Q blocks shares (sample, channel
-// slice); each member keeps its 256 / 512 pixel rows of the slice in registers -- x (and dy) are read from HBM exactly
-// once -- and the members exchange their per-channel partial sums through global memory inside the launch.  The
-// two-kernel path above reads x twice forward and x, dy twice backward: at batch 64 that was 671 MB per backward call
-// at 64x64x256 against 403 MB here.
-//   * Work ids come from an atomic ticket, so a cluster's members are Q consecutive block STARTS: whatever order the
-//     dispatcher picks, the oldest unfinished cluster has every member resident or next to start (needs only Q <= the
-//     number of resident blocks), and a waiting member never waits for a block that cannot start.
-//   * Exchange (MI355X_MICROARCH.md, inter-workgroup visibility): wave 0 publishes the block's partials with agent-scope
-//     (write-through) stores, drains them, one lane adds 1 to the cluster's arrival counter and polls it relaxed, one
-//     agent-scope acquire, barrier; the members' partials are then read with agent-scope loads in member order, so every
-//     member computes bit-identical totals.  Ticket and arrival words are zeroed by a memset ahead of every launch.
-//   * A poll that never completes gives up after ~2^22 sleeps (a wrong result in a test beats a hung GPU).
-// ---------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) unsigned gu32;
-#define MDM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-constexpr int GN_CL_PAYLOAD = 128;   // floats a member publishes (backward: A1, A2 of 64 channels; forward: 16 used)
-
-__device__ __forceinline__ unsigned gn_ticket(unsigned* ctr, unsigned* slot) {
-  if (threadIdx.x == 0) *slot = __hip_atomic_fetch_add((gu32*)(ctr), 1u, MDM_RLX_AGENT);
-  __syncthreads();
-  return *slot;
-}
-
-// wave 0 only: publish v0 / v1 (payload words lane, lane + 64), arrive, wait for the other members
-__device__ __forceinline__ void gn_cluster_exchange(float* mine, float v0, float v1, unsigned* arrive, int Q, int lane) {
-  gu32* const m = (gu32*)(mine);
-  __hip_atomic_store(m + lane, __float_as_uint(v0), MDM_RLX_AGENT);
-  __hip_atomic_store(m + 64 + lane, __float_as_uint(v1), MDM_RLX_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) {
-    gu32* const a = (gu32*)(arrive);
-    __hip_atomic_fetch_add(a, 1u, MDM_RLX_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(a, MDM_RLX_AGENT) < (unsigned)Q && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(8);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-}
-
-__device__ __forceinline__ float gn_cluster_load(const float* p) {
-  return __uint_as_float(__hip_atomic_load((const gu32*)(p), MDM_RLX_AGENT));
-}
-
-template <typename T, int ACT, int NI, int NTHR>
-__global__ __launch_bounds__(NTHR) void gn_cluster_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, const T* __restrict__ film,
-                                                              T* __restrict__ y, float* __restrict__ stats,
-                                                              float* __restrict__ coef, unsigned* ctr, float* cpart,
-                                                              int HW, int C, int G, int CB, int Q, float eps) {
-  constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = NTHR / LPR, NW = NTHR / 64, ROWS = NI * R;
-  __shared__ float sh[NW][LPR];
-  __shared__ float gsum[8], gm2[8], gmean[8], grstd[8];
-  __shared__ unsigned sh_w;
-  const unsigned w = gn_ticket(ctr, &sh_w);
-  const int nsl = C / CB;
-  const int cluster = (int)(w / (unsigned)Q), member = (int)w - cluster * Q;
-  const int n = cluster / nsl, cb0 = (cluster - n * nsl) * CB;
-  const int prow0 = member * ROWS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = tid % LPR, r = tid / LPR;
-  const int cpg = C / G, cpc = cpg / EPV, gpb = CB / cpg;
-  const bool active = c * EPV < CB;
-  const int ch0 = cb0 + c * EPV;
-  const int gl = active ? (c * EPV) / cpg : 0;
-  const T* xn = x + (size_t)n * HW * C + ch0;
-  uint4 raw[NI];
-  float s = 0.f;
-#pragma unroll
-  for (int it = 0; it < NI; ++it) {
-    const int p = prow0 + r + it * R;
-    raw[it] = uint4{0u, 0u, 0u, 0u};
-    if (active && p < HW) {
-      raw[it] = *reinterpret_cast<const uint4*>(xn + (size_t)p * C);
-      Chunk<T> v;
-      v.load(reinterpret_cast<const T*>(&raw[it]));
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) s += v.v[e];
-    }
-  }
-  s = rows_sum<LPR>(s);
-  if (lane < LPR) sh[wave][lane] = s;
-  __syncthreads();
-  if (tid < 8) {
-    float t = 0.f;
-    if (tid < gpb)
-      for (int ww = 0; ww < NW; ++ww)
-        for (int cc = tid * cpc; cc < (tid + 1) * cpc; ++cc) t += sh[ww][cc];
-    gsum[tid] = t;
-  }
-  __syncthreads();
-  // second moment about the BLOCK's own group mean (exact two-pass within the block; blocks are combined below)
-  const float cnt_b = (float)cpg * (float)min(ROWS, HW - prow0);
-  const float mu_b = gsum[gl] / cnt_b;
-  float q = 0.f;
-#pragma unroll
-  for (int it = 0; it < NI; ++it) {
-    const int p = prow0 + r + it * R;
-    if (active && p < HW) {
-      Chunk<T> v;
-      v.load(reinterpret_cast<const T*>(&raw[it]));
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) { const float d = v.v[e] - mu_b; q += d * d; }
-    }
-  }
-  q = rows_sum<LPR>(q);
-  __syncthreads();   // the first-moment reads of sh are done
-  if (lane < LPR) sh[wave][lane] = q;
-  __syncthreads();
-  if (tid < 8) {
-    float t = 0.f;
-    if (tid < gpb)
-      for (int ww = 0; ww < NW; ++ww)
-        for (int cc = tid * cpc; cc < (tid + 1) * cpc; ++cc) t += sh[ww][cc];
-    gm2[tid] = t;
-  }
-  __syncthreads();
-  float* const cl_part = cpart + (size_t)cluster * Q * GN_CL_PAYLOAD;
-  if (wave == 0)
-    gn_cluster_exchange(cl_part + (size_t)member * GN_CL_PAYLOAD, lane < 8 ? gsum[lane] : (lane < 16 ? gm2[lane - 8] : 0.f), 0.f,
-                        ctr + 1 + cluster, Q, lane);
-  __syncthreads();
-  if (tid < gpb) {
-    // Chan's combination over the members in member order: mean of the whole group, then M2 = sum(M2_b + n_b (mu_b - mu)^2)
-    const float cnt = (float)cpg * (float)HW;
-    float total = 0.f;
-    for (int m = 0; m < Q; ++m) total += gn_cluster_load(cl_part + (size_t)m * GN_CL_PAYLOAD + tid);
-    const float mu = total / cnt;
-    float m2 = 0.f;
-    for (int m = 0; m < Q; ++m) {
-      const float nb = (float)cpg * (float)min(ROWS, HW - m * ROWS);
-      const float d = gn_cluster_load(cl_part + (size_t)m * GN_CL_PAYLOAD + tid) / nb - mu;
-      m2 += gn_cluster_load(cl_part + (size_t)m * GN_CL_PAYLOAD + 8 + tid) + nb * d * d;
-    }
-    const float rstd = rsqrtf(fmaxf(m2 / cnt, 0.f) + eps);
-    gmean[tid] = mu; grstd[tid] = rstd;
-    if (member == 0) {
-      const int g = cb0 / cpg + tid;
-      stats[((size_t)n * G + g) * 2] = mu;
-      stats[((size_t)n * G + g) * 2 + 1] = rstd;
-    }
-  }
-  __syncthreads();
-  if (!active) return;
-  const float mu = gmean[gl], rstd = grstd[gl];
-  float a[EPV], b[EPV];
-#pragma unroll
-  for (int e = 0; e < EPV; ++e) {
-    const int ch = ch0 + e;
-    float f = 1.f, tb = 0.f;
-    if (film) { f = 1.f + to_f32(film[(size_t)n * 2 * C + ch]); tb = to_f32(film[(size_t)n * 2 * C + C + ch]); }
-    const float ga = gamma[ch], be = beta[ch];
-    a[e] = ga * f * rstd;
-    b[e] = (be - mu * rstd * ga) * f + tb;
-  }
-  if (r == 0 && member == 0) {
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-      coef[((size_t)n * C + ch0 + e) * 2] = a[e];
-      coef[((size_t)n * C + ch0 + e) * 2 + 1] = b[e];
-    }
-  }
-  T* yn = y + (size_t)n * HW * C + ch0;
-#pragma unroll
-  for (int it = 0; it < NI; ++it) {
-    const int p = prow0 + r + it * R;
-    if (p < HW) {
-      Chunk<T> v;
-      v.load(reinterpret_cast<const T*>(&raw[it]));
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        const float z = a[e] * v.v[e] + b[e];
-        v.v[e] = ACT ? silu_f(z) : z;
-      }
-      v.store(yn + (size_t)p * C);
-    }
-  }
-}
-
-template <typename T, int ACT, int NI, int NTHR>
-__global__ __launch_bounds__(NTHR) void gn_cluster_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              const T* __restrict__ film, const float* __restrict__ stats,
-                                                              const float* __restrict__ coef, T* __restrict__ dx,
-                                                              T* __restrict__ dfilm, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, const T* __restrict__ dres,
-                                                              const T* __restrict__ dres2, unsigned* ctr, float* cpart,
-                                                              int HW, int C, int G, int CB, int Q, int pstride) {
-  constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = NTHR / LPR, NW = NTHR / 64, ROWS = NI * R;
-  constexpr int NV = LPR * 2 * EPV;
-  static_assert(NV == GN_CL_PAYLOAD, "a member publishes 128 floats");
-  __shared__ float sh[NW][NV];     // [wave][chunk lane][A1 x EPV, A2 x EPV]
-  __shared__ float tot[NV];
-  __shared__ float sg[LPR][2];
-  __shared__ unsigned sh_w;
-  const unsigned w = gn_ticket(ctr, &sh_w);
-  const int nsl = C / CB;
-  const int cluster = (int)(w / (unsigned)Q), member = (int)w - cluster * Q;
-  const int n = cluster / nsl, cb0 = (cluster - n * nsl) * CB;
-  const int prow0 = member * ROWS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = tid % LPR, r = tid / LPR;
-  const int cpg = C / G, cpc = cpg / EPV;
-  const bool active = c * EPV < CB;
-  const int ch0 = active ? cb0 + c * EPV : cb0;
-  const int gl = active ? (c * EPV) / cpg : 0;
-  const size_t base = (size_t)n * HW * C + ch0;
-  float a[EPV], b[EPV];
-#pragma unroll
-  for (int e = 0; e < EPV; ++e) {
-    a[e] = coef[((size_t)n * C + ch0 + e) * 2];
-    b[e] = coef[((size_t)n * C + ch0 + e) * 2 + 1];
-  }
-  uint4 rx[NI], rd[NI];
-  float A1[EPV], A2[EPV];
-#pragma unroll
-  for (int e = 0; e < EPV; ++e) { A1[e] = 0.f; A2[e] = 0.f; }
-#pragma unroll
-  for (int it = 0; it < NI; ++it) {
-    const int p = prow0 + r + it * R;
-    rx[it] = uint4{0u, 0u, 0u, 0u}; rd[it] = uint4{0u, 0u, 0u, 0u};
-    if (active && p < HW) {
-      rx[it] = *reinterpret_cast<const uint4*>(x + base + (size_t)p * C);
-      rd[it] = *reinterpret_cast<const uint4*>(dy + base + (size_t)p * C);
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < NI; ++it) {
-    Chunk<T> vx, vd;
-    vx.load(reinterpret_cast<const T*>(&rx[it]));
-    vd.load(reinterpret_cast<const T*>(&rd[it]));
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) {   // rows past the image hold dy = 0: they add nothing
-      float dz = vd.v[e];
-      if (ACT) dz *= dsilu_f(a[e] * vx.v[e] + b[e]);
-      A1[e] += dz; A2[e] += dz * vx.v[e];
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < EPV; ++e) { A1[e] = rows_sum<LPR>(A1[e]); A2[e] = rows_sum<LPR>(A2[e]); }
-  if (lane < LPR) {
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) { sh[wave][lane * 2 * EPV + e] = A1[e]; sh[wave][lane * 2 * EPV + EPV + e] = A2[e]; }
-  }
-  __syncthreads();
-  float* const cl_part = cpart + (size_t)cluster * Q * GN_CL_PAYLOAD;
-  if (wave == 0) {
-    float t0 = 0.f, t1 = 0.f;
-    for (int ww = 0; ww < NW; ++ww) { t0 += sh[ww][lane]; t1 += sh[ww][64 + lane]; }
-    gn_cluster_exchange(cl_part + (size_t)member * GN_CL_PAYLOAD, t0, t1, ctr + 1 + cluster, Q, lane);
-  }
-  __syncthreads();
-  if (tid < NV) {
-    float t = 0.f;
-    for (int m = 0; m < Q; ++m) t += gn_cluster_load(cl_part + (size_t)m * GN_CL_PAYLOAD + tid);
-    tot[tid] = t;
-  }
-  __syncthreads();
-  const int g = ch0 / cpg;
-  const float mu = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
-  float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-  for (int e = 0; e < EPV; ++e) {
-    const int ch = ch0 + e;
-    const float a1 = tot[c * 2 * EPV + e], a2 = tot[c * 2 * EPV + EPV + e];
-    const float Xh = rstd * (a2 - mu * a1);
-    float f = 1.f;
-    if (film) f = 1.f + to_f32(film[(size_t)n * 2 * C + ch]);
-    const float ga = gamma[ch], be = beta[ch];
-    if (r == 0 && active && member == 0) {
-      if (pstride) {
-        dgamma[(size_t)n * pstride + ch] = f * Xh;
-        dbeta[(size_t)n * pstride + ch] = f * a1;
-      } else {
-        unsafeAtomicAdd(dgamma + ch, f * Xh);
-        unsafeAtomicAdd(dbeta + ch, f * a1);
-      }
-      if (film) {
-        dfilm[(size_t)n * 2 * C + ch] = from_f32<T>(ga * Xh + be * a1);
-        dfilm[(size_t)n * 2 * C + C + ch] = from_f32<T>(a1);
-      }
-    }
-    p1 += f * ga * a1;
-    p2 += f * ga * Xh;
-  }
-  if (r == 0) { sg[c][0] = active ? p1 : 0.f; sg[c][1] = active ? p2 : 0.f; }
-  __syncthreads();
-  if (!active) return;
-  float S1 = 0.f, S2 = 0.f;
-  for (int cc = gl * cpc; cc < (gl + 1) * cpc; ++cc) { S1 += sg[cc][0]; S2 += sg[cc][1]; }
-  const float mm = (float)cpg * (float)HW;
-  const float qq = -rstd * rstd * S2 / mm;
-  const float rr = -rstd * S1 / mm - qq * mu;
-#pragma unroll
-  for (int it = 0; it < NI; ++it) {
-    const int p = prow0 + r + it * R;
-    if (p < HW) {
-      Chunk<T> vx, vd;
-      vx.load(reinterpret_cast<const T*>(&rx[it]));
-      vd.load(reinterpret_cast<const T*>(&rd[it]));
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        float dz = vd.v[e];
-        if (ACT) dz *= dsilu_f(a[e] * vx.v[e] + b[e]);
-        vd.v[e] = a[e] * dz + qq * vx.v[e] + rr;
-      }
-      if (dres) {
-        Chunk<T> vr;
-        vr.load(dres + base + (size_t)p * C);
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) vd.v[e] += vr.v[e];
-      }
-      if (dres2) {
-        Chunk<T> vr;
-        vr.load(dres2 + base + (size_t)p * C);
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) vd.v[e] += vr.v[e];
-      }
-      vd.store(dx + base + (size_t)p * C);
-    }
-  }
-}
-
-// Cluster geometry of a call (false = the cluster kernels do not apply): `ni` register passes of a 512-thread block.
-struct GnClusterCfg { int cb, q, nclusters; size_t ctr_floats; };
-static int g_gn_cluster = 1;   // development switch (mdm_dev_set_gn_cluster): 0 = always the two-kernel path, 2 = also for grids too small to pay (tests)
-static bool gn_cluster_cfg(int N, int HW, int C, int G, int dtype, int ni, GnClusterCfg* o) {
-  if (!g_gn_cluster) return false;
-  const int lpr = dtype == DT_F32 ? 16 : 8;
-  const int cb = gn_fused_cb(1, C, G, dtype, 1);
-  if (!cb) return false;
-  const int rows = ni * (512 / lpr);
-  const int q = (HW + rows - 1) / rows;
-  if (q < 2 || q > 32) return false;
-  const long blocks = (long)N * (C / cb) * q;
-  if (blocks < 512 && g_gn_cluster != 2) return false;   // too few blocks to fill the chip: the two-kernel path splits the pixels finer
-  o->cb = cb; o->q = q; o->nclusters = N * (C / cb);
-  o->ctr_floats = ((size_t)(1 + o->nclusters) + 63) / 64 * 64;
-  return true;
-}
-static size_t gn_cluster_ws_floats(int N, int HW, int C, int G) {
-  size_t best = 0;
-  for (int dtype = 0; dtype < 2; ++dtype)
-    for (int ni = 4; ni <= 8; ni += 4) {
-      GnClusterCfg c;
-      if (!gn_cluster_cfg(N, HW, C, G, dtype, ni, &c)) continue;
-      const size_t f = c.ctr_floats + (size_t)c.nclusters * c.q * GN_CL_PAYLOAD;
-      if (f > best) best = f;
-    }
-  return best;
-}
-
-// ---------------------------------------------------------------------------------
 // LayerNorm over the last dim D of [R, D]; one 256-thread block per row.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float block_sum(float v, float* sh) {
@@ -1211,18 +859,11 @@ static inline int gn_pix_splits(int N, int HW, int cslices) {
   return sp;
 }
 
-// workspace (bytes, fp32): part [N][slabs][C][2] of the two-kernel path, or the cluster kernels' ticket / arrival words
-// followed by [cluster][member][128] partials -- whichever is larger
+// workspace (bytes, fp32): part [N][slabs][C][2]
 extern "C" int mdm_gn_plan(int N, int HW, int C, int G, size_t* ws_bytes) {
   MDM_CHECK_ARG(ws_bytes);
   const int slabs = gn_slabs(N, HW);
-  size_t floats = (size_t)N * slabs * C * 2;
-  const int keep = g_gn_cluster;
-  g_gn_cluster = 2;   // the plan covers both paths whatever the development switch says
-  const size_t cl = gn_cluster_ws_floats(N, HW, C, G);
-  g_gn_cluster = keep;
-  if (cl > floats) floats = cl;
-  *ws_bytes = floats * sizeof(float);
+  *ws_bytes = ((size_t)N * slabs * C * 2) * sizeof(float);
   return 0;
 }
 
@@ -1247,23 +888,6 @@ extern "C" int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, 
     if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_FWD(float, 1); } else { MDM_GN_FUSED_FWD(float, 0); } }
     else { if (act) { MDM_GN_FUSED_FWD(bf16, 1); } else { MDM_GN_FUSED_FWD(bf16, 0); } }
 #undef MDM_GN_FUSED_FWD
-    MDM_LAUNCH_STATUS();
-  }
-  GnClusterCfg cl;
-  if (gn_cluster_cfg(N, HW, C, G, dtype, 8, &cl)) {
-    unsigned* const ctr = reinterpret_cast<unsigned*>(ws);
-    float* const cpart = ws + cl.ctr_floats;
-    if (hipMemsetAsync(ctr, 0, cl.ctr_floats * sizeof(float), st) != hipSuccess) {
-      mdm_set_error(__FILE__, __LINE__, "hipMemsetAsync(cluster counters)");
-      return (int)hipGetLastError();
-    }
-    const dim3 grid((unsigned)(cl.nclusters * cl.q));
-#define MDM_GN_CL_FWD(TT, ACT)                                                                                      \
-    hipLaunchKernelGGL((gn_cluster_fwd_kernel<TT, ACT, 8, 512>), grid, dim3(512), 0, st, (const TT*)x, gamma, beta,   \
-                       (const TT*)film, (TT*)y, stats, coef, ctr, cpart, HW, C, G, cl.cb, cl.q, eps)
-    if (dtype == DT_F32) { if (act) { MDM_GN_CL_FWD(float, 1); } else { MDM_GN_CL_FWD(float, 0); } }
-    else { if (act) { MDM_GN_CL_FWD(bf16, 1); } else { MDM_GN_CL_FWD(bf16, 0); } }
-#undef MDM_GN_CL_FWD
     MDM_LAUNCH_STATUS();
   }
   const int slabs = gn_slabs(N, HW);
@@ -1318,24 +942,6 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
 #undef MDM_GN_FUSED_BWD
     MDM_LAUNCH_STATUS();
   }
-  GnClusterCfg cl;
-  if (gn_cluster_cfg(N, HW, C, G, dtype, 4, &cl)) {
-    unsigned* const ctr = reinterpret_cast<unsigned*>(ws);
-    float* const cpart = ws + cl.ctr_floats;
-    if (hipMemsetAsync(ctr, 0, cl.ctr_floats * sizeof(float), st) != hipSuccess) {
-      mdm_set_error(__FILE__, __LINE__, "hipMemsetAsync(cluster counters)");
-      return (int)hipGetLastError();
-    }
-    const dim3 grid((unsigned)(cl.nclusters * cl.q));
-#define MDM_GN_CL_BWD(TT, ACT)                                                                                      \
-    hipLaunchKernelGGL((gn_cluster_bwd_kernel<TT, ACT, 4, 512>), grid, dim3(512), 0, st, (const TT*)dy, (const TT*)x, \
-                       gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, dgamma, dbeta, (const TT*)dres, \
-                       (const TT*)dres2, ctr, cpart, HW, C, G, cl.cb, cl.q, pstride)
-    if (dtype == DT_F32) { if (act) { MDM_GN_CL_BWD(float, 1); } else { MDM_GN_CL_BWD(float, 0); } }
-    else { if (act) { MDM_GN_CL_BWD(bf16, 1); } else { MDM_GN_CL_BWD(bf16, 0); } }
-#undef MDM_GN_CL_BWD
-    MDM_LAUNCH_STATUS();
-  }
   const int slabs = gn_slabs(N, HW);
   const int pps = (HW + slabs - 1) / slabs;
   const int cb = gn_slice(C, G, epv);
@@ -1354,8 +960,6 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
 #undef MDM_GN_BWD
   MDM_LAUNCH_STATUS();
 }
-
-extern "C" int mdm_dev_set_gn_cluster(int mode) { g_gn_cluster = mode < 0 || mode > 2 ? 1 : mode; return 0; }
 
 // ---- per-sample GroupNorm parameter-gradient rows -> gradient slots, many layers per launch ------------------------
 // Entry l: dgamma_l[c] += sum_n pg_l[n][c], dbeta_l[c] += sum_n pb_l[n][c] (fixed order: deterministic).  One block per

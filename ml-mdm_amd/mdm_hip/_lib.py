@@ -138,8 +138,6 @@ def _apply_dev_env(handle):
         handle.mdm_dev_set_knob(6, int(os.environ["MDM_HIP_SPLIT_FILL"]))
     if os.environ.get("MDM_HIP_CONV_DIRECT") == "0":
         handle.mdm_dev_set_knob(7, 1)
-    if os.environ.get("MDM_HIP_GN_CLUSTER") == "0":   # GroupNorm of large images by the two-kernel path
-        handle.mdm_dev_set_gn_cluster(0)
     if os.environ.get("MDM_HIP_GEMM_X") == "2":   # conv_gemm_x_kernel whenever the problem allows (default: never)
         handle.mdm_dev_set_knob(3, 2)
 
