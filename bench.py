@@ -44,7 +44,7 @@ FWD_GFLOP_PER_SAMPLE = {"unet64": 363.9, "nested256": 589.1, "mini": 0.0}
 PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0       # HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s measured for a float4 copy)
-PMC_FILES = ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
+PMC_FILES = ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
 
 
 def build(workload, device, seed=0):
@@ -184,11 +184,21 @@ def timed_steps(step, sample, warmup, steps, sync):
     for _ in range(warmup):
         step(sample)
     sync()
+    # BENCH_STEP_TIMES=1 (diagnostic): a HIP event after every timed step, read back after the closing sync -- the
+    # per-step GPU intervals go to stderr, the timed region itself is unchanged
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if os.environ.get("BENCH_STEP_TIMES") else None
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if evs:
+        evs[0].record()
+    for i in range(steps):
         step(sample)
+        if evs:
+            evs[i + 1].record()
     sync()
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if evs:
+        print("per-step ms: " + " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(steps)), file=sys.stderr)
+    return dt
 
 
 def main():
