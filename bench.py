@@ -25,6 +25,7 @@ The timed step IS ``mdm_hip.trainer.train_batch`` -- the reference's ``trainer.t
 ModelEma 0.9999, gradient_clip_norm 2, bf16 autocast): one import swap in the CLI gives this number.
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -187,6 +188,12 @@ def timed_steps(step, sample, warmup, steps, sync):
     # BENCH_STEP_TIMES=1 (diagnostic): a HIP event after every timed step, read back after the closing sync -- the
     # per-step GPU intervals go to stderr, the timed region itself is unchanged
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if os.environ.get("BENCH_STEP_TIMES") else None
+    # The cyclic garbage collector stays out of the timed region (collected before, re-enabled after; reference counting
+    # frees the step's tensors as always): a generation-2 pass over the module / autograd object graph is a 100+ ms host
+    # stall at a random step (the suspected cause of two of this round's twelve runs reading 107-108 ms where the same box
+    # then gave 93-94).
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     if evs:
         evs[0].record()
@@ -196,6 +203,7 @@ def timed_steps(step, sample, warmup, steps, sync):
             evs[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     if evs:
         print("per-step ms: " + " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(steps)), file=sys.stderr)
     return dt

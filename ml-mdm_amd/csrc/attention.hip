@@ -788,6 +788,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     // The 64 staged queries go through in two halves of 32 (hh = the (kt >> 1) half of perm_row, which is also the
     // reduction half of the transposed fragments): only two score tiles per key tile are live at a time, which is
     // what lets a wave own KT = 2 key tiles -- every Q / dO fragment read from LDS then feeds two MFMAs.
+    // A wave without a single real key skips the arithmetic of the tile (one branch around the whole body); a dead
+    // SECOND tile is computed anyway -- its K / V fragments are zeros and its keys are masked, so it adds nothing.  A
+    // branch per MFMA pair (round 3) cut the loop into ~60 basic blocks of two MFMAs each; as one region the body is
+    // 64 MFMAs + 204 VALU + 56 LDS reads that the scheduler interleaves -- measured time unchanged (0.87 ms at
+    // L = 1024, d = 64, batch 64): the kernel is bound by its LDS fragment traffic and barriers, not by issue order.
+    if (tile_live[0]) {
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       f32x4 s[KT][2], dp[KT][2];
@@ -802,11 +808,10 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
           load_frag<T>(a, Qs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
           load_frag<T>(g, Gs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
 #pragma unroll
-          for (int kk = 0; kk < KT; ++kk)
-            if (tile_live[kk]) {
-              mma16(s[kk][k2], a, kf[kk][ks]);
-              mma16(dp[kk][k2], g, vf[kk][ks]);
-            }
+          for (int kk = 0; kk < KT; ++kk) {
+            mma16(s[kk][k2], a, kf[kk][ks]);
+            mma16(dp[kk][k2], g, vf[kk][ks]);
+          }
         }
       }
       // lane: key = l16 (column), query positions hh*32 + quad*8 + k2*4 + i
@@ -839,12 +844,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(At
           load_frag_T<T, D>(a, Qs, QTs, dt, hh, quad, l16);
         }
 #pragma unroll
-        for (int kk = 0; kk < KT; ++kk)
-          if (tile_live[kk]) {
-            mma16(dv[kk][dt], g, pf[kk]);
-            mma16(dk[kk][dt], a, dsf[kk]);
-          }
+        for (int kk = 0; kk < KT; ++kk) {
+          mma16(dv[kk][dt], g, pf[kk]);
+          mma16(dk[kk][dt], a, dsf[kk]);
+        }
       }
+    }
     }
     if constexpr (PF) {
       if (q0 + 64 < p.L) {
@@ -1013,13 +1018,12 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
     const T* Vp = reinterpret_cast<const T*>(pass ? p.vc : p.v) + (size_t)b * (pass ? p.c_bs : p.k_bs) + (size_t)h * D;
     const int rs = pass ? p.c_rs : p.k_rs;
     int key[KT];
-    bool key_ok[KT], key_live[KT], tile_live[KT];
+    bool key_ok[KT], key_live[KT];
     Frag<T> kf[KT][DS], vf[KT][DS];
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) {
       key[kk] = g0 + kk * 16 + l16;
       key_ok[kk] = key[kk] < nk;
-      tile_live[kk] = __builtin_amdgcn_readfirstlane(g0 + kk * 16) < nk;
 #pragma unroll
       for (int ks = 0; ks < DS; ++ks) {
         frag_from_global<T>(kf[kk][ks], Kp + (size_t)(key_ok[kk] ? key[kk] : 0) * rs + ks * 32 + quad * 8, key_ok[kk]);
@@ -1052,11 +1056,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
             load_frag<T>(a, Qs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
             load_frag<T>(g, Gs + (ks / KSTEPS) * (64 * 128), row, ks % KSTEPS, quad);
 #pragma unroll
-            for (int kk = 0; kk < KT; ++kk)
-              if (tile_live[kk]) {
-                mma16(s[kk][k2], a, kf[kk][ks]);
-                mma16(dp[kk][k2], g, vf[kk][ks]);
-              }
+            for (int kk = 0; kk < KT; ++kk) {   // (a dead second tile holds zero fragments and masked keys: no branch)
+              mma16(s[kk][k2], a, kf[kk][ks]);
+              mma16(dp[kk][k2], g, vf[kk][ks]);
+            }
           }
         }
         // lane: key = l16 (column), query positions qt*64 + hh*32 + quad*8 + k2*4 + i
@@ -1084,11 +1087,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
           troff.read(g, Gs, dt, hh);
           troff.read(a, Qs, dt, hh);
 #pragma unroll
-          for (int kk = 0; kk < KT; ++kk)
-            if (tile_live[kk]) {
-              mma16(dv[kk][dt], g, pf[kk]);
-              mma16(dk[kk][dt], a, dsf[kk]);
-            }
+          for (int kk = 0; kk < KT; ++kk) {
+            mma16(dv[kk][dt], g, pf[kk]);
+            mma16(dk[kk][dt], a, dsf[kk]);
+          }
         }
       }
     }
@@ -1173,6 +1175,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
             mma16(dp[kt], vf[ks], gf[ks]);
           }
         }
+        // (the variant test stays between the score MFMAs and the softmax here: as one straight-line region per variant,
+        // as in attn_bwd_dq_kernel, this phase spills 41 registers at d = 96)
         if ((k0 + 64 <= nk) && !mrow) {   // full, unmasked tile (block-uniform): no per-key predicate
 #pragma unroll
           for (int kt = 0; kt < 4; ++kt)
