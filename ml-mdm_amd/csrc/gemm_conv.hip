@@ -2071,6 +2071,7 @@ static bool conv_bl_ok(const ConvArgs& a) {
 // of the nested model's inner U-Net at batch 16 (M = 4096: 192 tiles of 128x128 at N = 768), 25 was the sampling-only rule.
 static int g_split_fill = 80;   // development knob 6
 static int g_no_direct = 0;     // development knob 7: 1 = narrow 3x3 convolutions back on the implicit-GEMM kernel
+static int g_no_wgrad_direct = 0;   // development knob 8 (mdm_dev_set_knob): 1 = no wgrad_direct_kernel (split GEMM for the narrow weight gradients too)
 static int conv_ksplit(int M, int Cout, int K, int dtype) {
   if (dtype != DT_BF16 || K % 64 != 0 || Cout % 8 != 0 || Cout <= 64) return 1;
   const int fill = g_split_fill;   // development knob 6 (mdm_dev_set_knob), default 80
@@ -2594,7 +2595,8 @@ extern "C" int mdm_linear_grouped(const void* const* x, const void* const* w_pac
 }
 
 extern "C" int mdm_dev_set_knob(int idx, int value) {
-  MDM_CHECK_ARG(idx >= 0 && idx < 8);
+  MDM_CHECK_ARG(idx >= 0 && idx < 9);
+  if (idx == 8) { g_no_wgrad_direct = value; return 0; }
   if (idx == 3) { g_force_x = value; return 0; }
   if (idx == 6) { g_split_fill = value > 0 ? value : 80; return 0; }
   if (idx == 7) { g_no_direct = value; return 0; }
@@ -2603,12 +2605,199 @@ extern "C" int mdm_dev_set_knob(int idx, int value) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdm::g_knobs), &value, sizeof(int), idx * sizeof(int));
 }
 
+// ---- direct weight gradient for the narrow outer levels of the nested models (64 output channels at 128^2 ... 1024^2) ----
+// dW[64][9 x 64] of a 3x3 64 -> 64 convolution over a million pixels is an HBM
+// problem: x and dY are 134 MB each at batch 16, 256^2, the product is 37 K numbers.  The split GEMM above pads the 64
+// output channels to a 128-wide tile and walks K = 576 in five column tiles, each of which streams dY again and its
+// shifted copy of x through L2 -- 345 us per layer against a 60 us HBM bound (profiles/r04_shapes_nested256.txt, 5.8 ms
+// of the nested 64+256 step).  Here a block owns the WHOLE 64 x K gradient in registers and streams pixel tiles past it:
+//   * a TH x 32 pixel tile of dY and the (TH + 2) x 34 halo of x are staged in LDS once (HBM -> registers -> LDS, the next
+//     tile's loads in flight under this tile's MFMAs); the nine taps are nine shifted views of the halo;
+//   * the reduction index is the PIXEL, so both MFMA operands are read with the LDS transpose read from the natural
+//     [pixel][channel] images (lane i of a 16-lane group supplies pixel i >> 2, 4-channel segment i & 3 and receives
+//     channel i: 8 consecutive pixels of one channel per lane = one operand of v_mfma_f32_16x16x32_bf16).  The pixel
+//     pitch is padded so that the eight 32-byte rows one 32-lane half reads (pixels p .. p+3 and p+8 .. p+11) fall on
+//     eight disjoint 8-bank windows: pitch / 4 = 20 or 52 (mod 64);
+//   * 8 waves = 2 halves of the output channels x 4 quarters of the K columns; A = x^T fragment (16 K columns), B = dY^T
+//     fragment (16 output channels), so a lane ends up with 4 consecutive K columns of one output channel (16-byte stores);
+//   * every block writes ONE slab [64][K] (and its column sums of dY for the bias gradient) after its last tile; the
+//     slabs are added by mdm_conv_wgrad_reduce like the split ranges of the GEMM path.
+// Measured (nested 64+256, batch 16): 345 -> 155 us per layer (500 TF, 1.7 TB/s of operands); what is left is one exposed
+// memory round trip per tile -- the staging registers leave room for ONE tile of prefetch.  The nested model's step does
+// not move (59.4 vs 59.4 ms, alternating): its weight gradients run on the side stream, which is not its critical path.
+struct WgDirectArgs {
+  const bf16* x; const bf16* dy; float* slab; float* bslab;
+  int N, H, W, tiles_x, tiles_y, tiles;
+};
+constexpr int wgd_pitch(int bytes) {
+  int d = bytes / 4;
+  while (d % 64 != 20 && d % 64 != 52) ++d;
+  return d * 4;
+}
+typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
+__device__ __forceinline__ Frag<bf16> wgd_tr2(const char* p, int second) {
+  const wg_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)(p));
+  const wg_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)(p + second));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  Frag<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, v);
+  return f;
+}
+
+template <int CIN, int TAPS, int TH>
+__global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WgDirectArgs p) {
+  constexpr int COUT = 64, TW = 32, HALO = TAPS == 9 ? 1 : 0;
+  constexpr int TWH = TW + 2 * HALO, THH = TH + 2 * HALO;
+  constexpr int XCH = CIN / 8, DCH = COUT / 8;                       // 16-byte chunks per pixel
+  constexpr int PX = wgd_pitch(CIN * 2), PD = wgd_pitch(COUT * 2);   // bytes per staged pixel
+  constexpr int K = TAPS * CIN;
+  constexpr int NBW = K / 16 / 4;                                    // 16-column blocks of dW per wave
+  static_assert((K / 16) % 4 == 0, "K columns split over 4 waves");
+  constexpr int XROW = TWH * XCH, XCHUNKS = THH * XROW, DCHUNKS = TH * TW * DCH;
+  constexpr int NXL = (XCHUNKS + 511) / 512, NDL = (DCHUNKS + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  char* const xs = dsm;
+  char* const ys = dsm + THH * TWH * PX;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int mw = wid >> 2, nw = wid & 3;
+
+  // per-lane offsets of the transpose reads: pixel 8 quad + (l15 >> 2) of a 32-pixel row segment, 4-channel segment l15 & 3
+  const int trow = 8 * quad + (l15 >> 2), tseg = (l15 & 3) * 8;
+  int y_off[2], x_off[NBW];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) y_off[mi] = trow * PD + (mw * 2 + mi) * 32 + tseg;
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int nbg = nw * NBW + nb, tap = nbg / (CIN / 16), cb = nbg - tap * (CIN / 16);
+    const int dy_ = TAPS == 9 ? tap / 3 : 0, dx_ = TAPS == 9 ? tap % 3 : 0;
+    x_off[nb] = (dy_ * TWH + dx_ + trow) * PX + cb * 32 + tseg;
+  }
+
+  f32x4 acc[NBW][2];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) acc[nb][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  const bool do_bias = p.bslab != nullptr && nw == 0;   // wave-uniform
+
+  uint4 prex[NXL], prey[NDL];
+  auto issue = [&](int tile) {
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
+    const int gx0 = tx * TW - HALO, gy0 = ty * TH - HALO;
+    const bf16* xn = p.x + (size_t)n * p.H * p.W * CIN;
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      const int c = tid + 512 * i;
+      const int row = c / XROW, col = c - row * XROW, px = col / XCH, ch = col - px * XCH;
+      const int gy = gy0 + row, gx = gx0 + px;
+      prex[i] = uint4{0u, 0u, 0u, 0u};
+      if (c < XCHUNKS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+        prex[i] = *reinterpret_cast<const uint4*>(xn + ((size_t)gy * p.W + gx) * CIN + ch * 8);
+    }
+    const bf16* yn = p.dy + (((size_t)n * p.H + ty * TH) * p.W + tx * TW) * COUT;
+#pragma unroll
+    for (int i = 0; i < NDL; ++i) {
+      const int c = tid + 512 * i;
+      const int row = c / (TW * DCH), col = c - row * (TW * DCH);
+      prey[i] = uint4{0u, 0u, 0u, 0u};
+      if (c < DCHUNKS) prey[i] = *reinterpret_cast<const uint4*>(yn + (size_t)row * p.W * COUT + col * 8);
+    }
+  };
+  if ((int)blockIdx.x < p.tiles) issue(blockIdx.x);
+  for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      const int c = tid + 512 * i;
+      const int row = c / XROW, col = c - row * XROW, px = col / XCH, ch = col - px * XCH;
+      if (c < XCHUNKS) *reinterpret_cast<uint4*>(xs + (row * TWH + px) * PX + ch * 16) = prex[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NDL; ++i) {
+      const int c = tid + 512 * i;
+      const int pix = c / DCH, ch = c - pix * DCH;
+      if (c < DCHUNKS) *reinterpret_cast<uint4*>(ys + pix * PD + ch * 16) = prey[i];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < p.tiles) issue(tile + gridDim.x);
+#pragma unroll 2
+    for (int r = 0; r < TH; ++r) {
+      Frag<bf16> yf[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) yf[mi] = wgd_tr2(ys + r * (TW * PD) + y_off[mi], 4 * PD);
+      if (do_bias) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) bsum[mi] = frag_sum(yf[mi], bsum[mi]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        const Frag<bf16> xf = wgd_tr2(xs + r * (TWH * PX) + x_off[nb], 4 * PX);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) mma16(acc[nb][mi], xf, yf[mi]);
+      }
+    }
+    __syncthreads();   // the next tile's staging overwrites what the slower waves may still read
+  }
+  // acc[nb][mi][i] = dW[cout = (mw * 2 + mi) * 16 + l15][k = (nw * NBW + nb) * 16 + quad * 4 + i]
+  float* const S = p.slab + (size_t)blockIdx.x * COUT * K;
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+      *reinterpret_cast<f32x4*>(S + (size_t)((mw * 2 + mi) * 16 + l15) * K + (nw * NBW + nb) * 16 + quad * 4) = acc[nb][mi];
+  if (do_bias) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      float v = bsum[mi];                     // the four quads hold the four 8-pixel groups of every row segment
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (quad == 0) p.bslab[(size_t)blockIdx.x * COUT + (mw * 2 + mi) * 16 + l15] = v;
+    }
+  }
+}
+
+// slabs (= blocks) of the direct kernel for a problem, 0 = not a shape it is built for.  Decided from (M, Cout, K) alone so
+// that mdm_conv_wgrad and mdm_conv_wgrad_reduce agree; a problem of these sizes whose geometry the kernel cannot take
+// (1x1 with Cin = 576, an image not made of 8 x 32 tiles) runs the split GEMM with the same number of ranges.
+constexpr int WGD_SLABS = 256;
+static int wgrad_direct_slabs(int M, int Cout, int K, int dtype) {
+  if (g_no_wgrad_direct || dtype != DT_BF16 || Cout != 64 || M < 262144) return 0;
+  return (K == 576 || K == 128 || K == 192) ? WGD_SLABS : 0;
+}
+static bool wgrad_direct_ok(const WgradArgs& a, int ksize) {
+  if (a.stride != 1 || a.Ho != a.H || a.Wo != a.W || a.Cout != 64 || a.skip_cout) return false;
+  // 3x3 only.  The 1x1 shortcuts (128 / 192 -> 64) have 4-6 MFMAs per wave and tile row: there the tile loop is one
+  // exposed memory round trip per 256 pixels (261 us measured) and the split GEMM with the same 256 ranges is faster
+  // (225 us; 448 us with the 10-range split the cost model gave it before).
+  if (!(ksize == 3 && a.Cin == 64)) return false;
+  if (((uintptr_t)a.x & 15) || ((uintptr_t)a.dy & 15)) return false;
+  if (a.H % 8 != 0 || a.W % 32 != 0) return false;
+  return (long)a.N * (a.H / 8) * (a.W / 32) >= WGD_SLABS;
+}
+template <int CIN, int TAPS, int TH>
+static int launch_wgrad_direct(const WgradArgs& a, hipStream_t st) {
+  constexpr int HALO = TAPS == 9 ? 1 : 0;
+  constexpr int smem = (TH + 2 * HALO) * (32 + 2 * HALO) * wgd_pitch(CIN * 2) + TH * 32 * wgd_pitch(128);
+  static_assert(smem <= 160 * 1024, "LDS");
+  auto kern = wgrad_direct_kernel<CIN, TAPS, TH>;
+  ensure_dynamic_lds(kern, smem);
+  WgDirectArgs d;
+  d.x = (const bf16*)a.x; d.dy = (const bf16*)a.dy; d.slab = a.slab; d.bslab = a.bslab;
+  d.N = a.N; d.H = a.H; d.W = a.W; d.tiles_x = d.W / 32; d.tiles_y = d.H / TH; d.tiles = d.tiles_x * d.tiles_y * d.N;
+  hipLaunchKernelGGL(kern, dim3(WGD_SLABS), dim3(512), smem, st, d);
+  MDM_NOTE_KERNEL("wgrad_direct_kernel<%d, %d, %d>", CIN, TAPS, TH);
+  MDM_LAUNCH_STATUS();
+}
+
 // workspace size (bytes) the caller must provide to mdm_conv_wgrad
 // Tile edge (128: 4 waves, 2 blocks / CU; 256: bf16 8-wave kernel, 1 block / CU) and split count of a problem, by a
 // small cost model in microseconds: rounds of resident blocks x (reduction tiles per split x tile time + per-block
 // prologue and slab write) + the slab traffic of the reduce kernel.  Replaces "about 2 blocks per CU": at
 // Cout x K = 768 x 3072 that rule gave 15 splits = 540 blocks = 2.1 rounds of the 256 CUs.
 static void wgrad_choose(int M, int Cout, int K, int dtype, int* te_out, int* splits_out) {
+  if (const int slabs = wgrad_direct_slabs(M, Cout, K, dtype)) { *te_out = 128; *splits_out = slabs; return; }
   const int bkm = dtype == DT_F32 ? 32 : 64;
   const int mt_total = (M + bkm - 1) / bkm;
   double best = 1e30;
@@ -2685,6 +2874,9 @@ static int conv_wgrad_impl(const void* x, const void* dy, int want_bias, float* 
   const int te = wgrad_tile(a.M, Cout, a.K, dtype);
   const int tiles = ((Cout + te - 1) / te) * ((a.K + te - 1) / te);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (wgrad_direct_slabs(a.M, Cout, a.K, dtype) && wgrad_direct_ok(a, ksize)) {
+    return launch_wgrad_direct<64, 9, 8>(a, st);
+  }
   constexpr int smem = 4 * 128 * 128, smem_big = 4 * 64 * 512;
   ensure_dynamic_lds(conv_wgrad_kernel<float, MODE_1x1>, smem);
   ensure_dynamic_lds(conv_wgrad_kernel<float, MODE_3x3>, smem);

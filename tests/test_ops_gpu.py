@@ -78,6 +78,11 @@ def nchw(t_nhwc):
         (2, 136, 256, 32, 64, 3, 1),    # 17 tile rows, two output-channel halves per block
         (4, 128, 128, 64, 32, 3, 1),    # 32-pixel-wide tiles, padded LDS rows
         (1, 256, 256, 64, 64, 3, 1),
+        # 64 output channels, >= 262144 pixels in 8 x 32 tiles (bf16): the direct weight gradient (wgrad_direct_kernel):
+        # one [64][taps * Cin] slab per block, both operands by LDS transpose reads of the staged pixel tile
+        (4, 256, 256, 64, 64, 3, 1),    # 3x3: halo of x, image borders on all four sides of the tile grid
+        (2, 264, 512, 64, 64, 3, 1),    # 33 tile rows: blocks with different tile counts
+        (4, 256, 256, 128, 64, 1, 1),   # 1x1 shortcut of the skip concatenation: the split GEMM with 256 ranges
     ],
 )
 def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
@@ -105,6 +110,39 @@ def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
     assert relerr(wd.grad, w.grad) < tol
     assert relerr(bd.grad, b.grad) < tol
     assert relerr(nchw(rd.grad), res.grad) < tol
+
+
+@pytest.mark.parametrize("N,H,W,Cin,ks", [(4, 256, 256, 64, 3), (2, 264, 512, 64, 3)])
+def test_conv_wgrad_direct_kernel(N, H, W, Cin, ks):
+    """The narrow weight gradients of the nested models' outer levels (64 output channels, a million pixels): the direct
+    kernel is what runs, and its result equals the split GEMM's (development knob 8) to summation-order rounding -- both
+    against the same bf16 operands; test_conv_fwd_bwd holds the same shapes against torch fp32."""
+    from mdm_hip import _lib, ops
+
+    g = torch.Generator().manual_seed(21)
+    dtype = torch.bfloat16
+    x = (torch.randn(N, H, W, Cin, generator=g)).to(dtype).to(dev())
+    w = (torch.randn(64, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)).to(dev())
+    b = torch.randn(64, generator=g).to(dev())
+    gy = torch.randn(N, H, W, 64, generator=g).to(dtype).to(dev())
+
+    def grads(knob):
+        _lib.lib().mdm_dev_set_knob(8, knob)
+        try:
+            wd, bd = w.clone().requires_grad_(), b.clone().requires_grad_()
+            y = ops.conv(x, wd, bd)
+            ops.profile_begin()
+            y.backward(gy)
+            names = list(ops.profile_end(2516.6)["all_gemm_kernels"])
+            return wd.grad, bd.grad, names
+        finally:
+            _lib.lib().mdm_dev_set_knob(8, 0)
+
+    dw, db, names = grads(0)
+    assert any("wgrad_direct_kernel" in n for n in names), names
+    dw_ref, db_ref, names_ref = grads(1)
+    assert not any("wgrad_direct_kernel" in n for n in names_ref), names_ref
+    assert relerr(dw, dw_ref) < 2e-5 and relerr(db, db_ref) < 2e-5
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,ks,stride", [(2, 16, 16, 256, 320, 3, 1), (3, 24, 20, 136, 200, 1, 1), (2, 18, 22, 64, 40, 3, 2),
