@@ -239,10 +239,10 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict
       float ab[2 * EPV];
 #pragma unroll
       for (int e = 0; e < 2 * EPV; ++e) ab[e] = cf[e];
-      for (int p = p_begin + tr; p < p_end; p += 2 * rows_par) {   // two rows (four loads) in flight, same summation order
-        uint4 rx[2], rd[2];
+      for (int p = p_begin + tr; p < p_end; p += 4 * rows_par) {   // four rows (eight loads) in flight, same summation order
+        uint4 rx[4], rd[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
           const int pu = p + u * rows_par;
           if (pu < p_end) {
             const size_t off = nbase + (size_t)pu * C + (size_t)(c0 + tc) * EPV;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict
           }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
           if (p + u * rows_par < p_end) {
             Chunk<T> cx, cd;
             cx.load(reinterpret_cast<const T*>(&rx[u]));
@@ -355,30 +355,51 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   }
   const int px0 = blockIdx.x * pix_per_block, px1 = min(HW, px0 + pix_per_block);
   const size_t base = (size_t)n * HW * C + cb0 + cl * EPV;
-  for (int p = px0 + rl; p < px1; p += rows_par) {
-    const size_t off = base + (size_t)p * C;
-    Chunk<T> cx, cd;
-    cx.load(x + off);
-    cd.load(dy + off);
+  // Four pixel rows per trip, every operand of the four requested before the first is used (8-16 loads of 16 bytes in
+  // flight per thread): one row per trip -- two dependent-latency loads, then the arithmetic, then the store -- left this
+  // kernel at 2.3-3.1 TB/s of its own traffic where the forward apply kernel (same map, four rows deep) reaches 5.
+  for (int p = px0 + rl; p < px1; p += 4 * rows_par) {
+    uint4 rx[4], rd[4], rr[4], rs[4];
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-      float dz = cd.v[e];
-      if (ACT) dz *= dsilu_f(a[e] * cx.v[e] + b[e]);
-      cd.v[e] = a[e] * dz + q[e] * cx.v[e] + r[e];
+    for (int u = 0; u < 4; ++u) {
+      const int pu = p + u * rows_par;
+      if (pu < px1) {
+        const size_t off = base + (size_t)pu * C;
+        rx[u] = *reinterpret_cast<const uint4*>(x + off);
+        rd[u] = *reinterpret_cast<const uint4*>(dy + off);
+        if (dres) rr[u] = *reinterpret_cast<const uint4*>(dres + off);
+        if (dres2) rs[u] = *reinterpret_cast<const uint4*>(dres2 + off);
+      }
     }
-    if (dres) {
-      Chunk<T> cr;
-      cr.load(dres + off);
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) cd.v[e] += cr.v[e];
-    }
-    if (dres2) {   // a second consumer of x outside the block (the U-Net's skip connection)
-      Chunk<T> cr;
-      cr.load(dres2 + off);
+    for (int u = 0; u < 4; ++u) {
+      const int pu = p + u * rows_par;
+      if (pu < px1) {
+        const size_t off = base + (size_t)pu * C;
+        Chunk<T> cx, cd;
+        cx.load(reinterpret_cast<const T*>(&rx[u]));
+        cd.load(reinterpret_cast<const T*>(&rd[u]));
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) cd.v[e] += cr.v[e];
+        for (int e = 0; e < EPV; ++e) {
+          float dz = cd.v[e];
+          if (ACT) dz *= dsilu_f(a[e] * cx.v[e] + b[e]);
+          cd.v[e] = a[e] * dz + q[e] * cx.v[e] + r[e];
+        }
+        if (dres) {
+          Chunk<T> cr;
+          cr.load(reinterpret_cast<const T*>(&rr[u]));
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) cd.v[e] += cr.v[e];
+        }
+        if (dres2) {   // a second consumer of x outside the block (the U-Net's skip connection)
+          Chunk<T> cr;
+          cr.load(reinterpret_cast<const T*>(&rs[u]));
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) cd.v[e] += cr.v[e];
+        }
+        cd.store(dx + off);
+      }
     }
-    cd.store(dx + off);
   }
 }
 
