@@ -75,9 +75,10 @@ def nested1024_config(lm_dim: int = 2048) -> Nested2UNetConfig:
 
 
 # ---- reduced variants for parity tests (same topology class, minutes on CPU) ---------------
-def mini_unet_config(lm_dim: int = 64, nesting: bool = False, masked: int = 0) -> UNetConfig:
+def mini_unet_config(lm_dim: int = 64, nesting: bool = False, masked: int = 0, lm_head: int = 0) -> UNetConfig:
     """2 levels (32, 256 channels), self+cross attention with FFN at level 1 (head dim 32)."""
     return UNetConfig(
+        num_lm_head_layers=lm_head,
         num_resnets_per_resolution=[1, 1],
         attention_levels=[1],
         num_attention_layers=[0, 1],

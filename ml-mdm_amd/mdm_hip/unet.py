@@ -25,6 +25,7 @@ from dataclasses import dataclass, field
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 
@@ -300,6 +301,79 @@ class ResNetBlock(nn.Module):
 
 
 # --------------------------------------------------------------------------------------
+# LM head: self-attention blocks over the text states (reference unet.py:316-387, 425-446; ``num_lm_head_layers`` > 0).
+# Off the denoiser's hot path -- B x 32 tokens, once per sampling run / train step -- and no shipped config enables it:
+# LayerNorm and the linear layers are this package's kernels, the S x S token attention and the GELU are torch ops on the
+# same GPU tensors ("reference-PyTorch fallback" for these blocks).  Rotary position embeddings
+# (``pos_emb``, a third-party package in the reference) are only used by the temporal blocks and are not implemented.
+# --------------------------------------------------------------------------------------
+class SelfAttention1D(nn.Module):
+    def __init__(self, channels, num_heads=8, num_head_channels=-1, use_attention_ffn=False, pos_emb=False):
+        super().__init__()
+        if pos_emb:
+            raise NotImplementedError("rotary position embeddings (temporal blocks) are not implemented on the HIP path")
+        self.channels = channels
+        if num_head_channels == -1:
+            self.num_heads = num_heads
+        else:
+            assert channels % num_head_channels == 0
+            self.num_heads = channels // num_head_channels
+        self.norm = nn.LayerNorm(channels)
+        self.qkv = nn.Linear(channels, channels * 3)
+        self.proj_out = zero_module(nn.Linear(channels, channels))
+        self.ffn = None
+        if use_attention_ffn:
+            self.ffn = nn.Sequential(nn.LayerNorm(channels), nn.Linear(channels, 4 * channels), nn.GELU(),
+                                     zero_module(nn.Linear(4 * channels, channels)))
+
+    def attention(self, q, k, v, mask=None):
+        bs, length, width = q.shape
+        ch = width // self.num_heads
+        scale = 1 / math.sqrt(math.sqrt(ch))
+        q = q.reshape(bs, length, self.num_heads, ch)
+        k = k.reshape(bs, length, self.num_heads, ch)
+        weight = torch.einsum("bthc,bshc->bhts", q * scale, k * scale)
+        if mask is not None:
+            weight = weight.masked_fill(mask.view(mask.size(0), 1, 1, mask.size(1)) == 0, float("-inf"))
+        weight = torch.softmax(weight.float(), dim=-1).type(weight.dtype)
+        a = torch.einsum("bhts,bshc->bthc", weight, v.reshape(bs, -1, self.num_heads, ch))
+        return a.reshape(bs, length, -1)
+
+    def forward(self, x, mask):
+        qkv = ops.linear(ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps), self.qkv.weight, self.qkv.bias)
+        q, k, v = qkv.chunk(3, dim=-1)
+        h = self.attention(q, k, v, mask).contiguous()
+        x = ops.linear(h, self.proj_out.weight, self.proj_out.bias, residual=x)
+        if self.ffn is not None:
+            n, l1, _, l2 = self.ffn
+            h = F.gelu(ops.linear(ops.layer_norm(x, n.weight, n.bias, n.eps), l1.weight, l1.bias))
+            x = ops.linear(h, l2.weight, l2.bias, residual=x)
+        return x
+
+
+class MLP(nn.Module):
+    def __init__(self, channels, multiplier=4):
+        super().__init__()
+        self.main = nn.Sequential(nn.LayerNorm(channels), nn.Linear(channels, multiplier * channels), nn.GELU(),
+                                  zero_module(nn.Linear(multiplier * channels, channels)))
+
+    def forward(self, x):
+        n, l1, _, l2 = self.main
+        h = F.gelu(ops.linear(ops.layer_norm(x, n.weight, n.bias, n.eps), l1.weight, l1.bias))
+        return ops.linear(h, l2.weight, l2.bias, residual=x)
+
+
+class SelfAttention1DBlock(nn.Module):
+    def __init__(self, channels, num_heads=8, num_head_channels=-1, mlp_multiplier=4):
+        super().__init__()
+        self.attn = SelfAttention1D(channels, num_heads, num_head_channels)
+        self.mlp = MLP(channels, mlp_multiplier)
+
+    def forward(self, x, mask):
+        return self.mlp(self.attn(x, mask))
+
+
+# --------------------------------------------------------------------------------------
 # the model
 # --------------------------------------------------------------------------------------
 class UNet(nn.Module):
@@ -307,8 +381,6 @@ class UNet(nn.Module):
         super().__init__()
         if config.temporal_mode:
             raise NotImplementedError("temporal_mode is not implemented on the HIP path")
-        if config.num_lm_head_layers:
-            raise NotImplementedError("num_lm_head_layers > 0 is not implemented on the HIP path")
         self.config = config
         self.input_channels, self.output_channels = input_channels, output_channels
         self.input_conditioning_feature_dim = config.conditioning_feature_dim
@@ -402,7 +474,8 @@ class UNet(nn.Module):
         if has_cond:
             if config.conditioning_feature_proj_dim > 0:
                 self.lm_proj = nn.Linear(self.input_conditioning_feature_dim, config.conditioning_feature_dim)
-            self.lm_head = nn.ModuleList([])
+            self.lm_head = nn.ModuleList([SelfAttention1DBlock(config.conditioning_feature_dim)
+                                          for _ in range(config.num_lm_head_layers)])
         self.is_temporal = []
 
     # ---- bookkeeping identical in behaviour to the reference ---------------------------
@@ -451,7 +524,10 @@ class UNet(nn.Module):
         cond = ops.cast(conditioning, compute_dtype())
         if self.config.conditioning_feature_proj_dim > 0:
             cond = ops.linear(cond, self.lm_proj.weight, self.lm_proj.bias)
-        y = ops.masked_mean(cond, cond_mask)
+        for head in self.lm_head:   # reference :850-853
+            cond = head(cond, cond_mask if self.masked_cross_attention else None)
+        # reference :854-861: with an LM head and unmasked cross attention the mean runs over ALL tokens
+        y = ops.masked_mean(cond, None if (not self.masked_cross_attention and len(self.lm_head) > 0) else cond_mask)
         if not self.masked_cross_attention:
             cond_mask = None
         cond_emb = ops.linear(y, self.cond_emb.weight, None)

@@ -154,11 +154,37 @@ def time_embedding(sd, cfg, times, cond_emb, micros):
     return temb
 
 
+def _ln(sd, name, x, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], eps)
+
+
+def lm_head_block(sd, prefix, x, mask, heads=8):
+    """One SelfAttention1DBlock over the text tokens x [B, S, C] (models/unet.py:439-446): SelfAttention1D without rotary
+    embedding and without its own ffn (:316-387: LayerNorm, qkv, 8 heads of C / 8 channels, q and k scaled by d^-1/4,
+    key mask -> -inf, softmax in fp32 or wider, proj_out, residual), then MLP (:425-436: x + Linear(GELU(Linear(LN(x)))))."""
+    B, S, C = x.shape
+    d = C // heads
+    q, k, v = _linear(sd, prefix + ".attn.qkv", _ln(sd, prefix + ".attn.norm", x)).chunk(3, dim=-1)
+    sc = 1.0 / math.sqrt(math.sqrt(d))
+    qh, kh, vh = (t.reshape(B, S, heads, d).permute(0, 2, 1, 3) for t in (q * sc, k * sc, v))   # [B, heads, S, d]
+    w = qh @ kh.transpose(-1, -2)                                                             # [B, heads, query, key]
+    if mask is not None:
+        w = w.masked_fill(mask.reshape(B, 1, 1, S) == 0, float("-inf"))
+    w = torch.softmax(w.to(torch.promote_types(w.dtype, torch.float32)), dim=-1).to(w.dtype)
+    a = (w @ vh).permute(0, 2, 1, 3).reshape(B, S, C)
+    x = x + _linear(sd, prefix + ".attn.proj_out", a)
+    m = prefix + ".mlp.main"
+    return x + _linear(sd, m + ".3", F.gelu(_linear(sd, m + ".1", _ln(sd, m + ".0", x))))
+
+
 def conditioning_path(sd, cfg, conditioning, cond_mask):
-    """models/unet.py:847-865 (num_lm_head_layers == 0)."""
+    """models/unet.py:847-865."""
     if (cfg.conditioning_feature_proj_dim or -1) > 0:
         conditioning = _linear(sd, "lm_proj", conditioning)
-    if cond_mask is None:
+    n_head = int(getattr(cfg, "num_lm_head_layers", 0) or 0)
+    for i in range(n_head):
+        conditioning = lm_head_block(sd, "lm_head.%d" % i, conditioning, cond_mask if cfg.masked_cross_attention else None)
+    if cond_mask is None or (not cfg.masked_cross_attention and n_head > 0):
         y = conditioning.mean(dim=1)
     else:
         y = (cond_mask.unsqueeze(-1) * conditioning).sum(dim=1) / cond_mask.sum(dim=1, keepdim=True)

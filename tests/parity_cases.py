@@ -26,6 +26,8 @@ def _cfg(name):
     return {
         "mini_unet": configs.mini_unet_config,
         "mini_unet_masked": lambda: configs.mini_unet_config(masked=1),
+        "mini_unet_lmhead": lambda: configs.mini_unet_config(masked=1, lm_head=2),
+        "mini_unet_lmhead_nomask": lambda: configs.mini_unet_config(masked=0, lm_head=1),
         "mini_nested": configs.mini_nested_config,
         "mini_nested2": configs.mini_nested2_config,
     }[name]()
@@ -40,9 +42,13 @@ CASES = ["mini_unet", "mini_unet_masked", "mini_nested", "mini_nested2"]
 #   *_mixed   mixed-resolution batches: the higher resolutions run on a prefix of the batch only (bh < bl; the
 #             ``mixed_ratio`` slicing of diffusion.py:258-275 as the vision model sees it, nested_unet.py:186-212),
 #             with explicit micros as well
-EXTRA_CASES = ["mini_unet_micros", "mini_nested_mixed", "mini_nested2_mixed"]
+#   *_lmhead  round 4: ``num_lm_head_layers`` > 0 -- SelfAttention1DBlocks over the text states ahead of the conditioning
+#             (models/unet.py:316-387, 425-446, 850-861), with masked cross attention (key mask inside the head, masked
+#             mean) and without (no mask in the head, the mean over ALL tokens)
+EXTRA_CASES = ["mini_unet_micros", "mini_nested_mixed", "mini_nested2_mixed", "mini_unet_lmhead", "mini_unet_lmhead_nomask"]
 ALL_CASES = CASES + EXTRA_CASES
-_SIDES = {"mini_unet": [16], "mini_unet_masked": [16], "mini_nested": [32, 16], "mini_nested2": [64, 32, 16]}
+_SIDES = {"mini_unet": [16], "mini_unet_masked": [16], "mini_nested": [32, 16], "mini_nested2": [64, 32, 16],
+          "mini_unet_lmhead": [16], "mini_unet_lmhead_nomask": [16]}
 _MIXED_BATCH = {"mini_nested_mixed": [2, 3], "mini_nested2_mixed": [1, 2, 3]}   # samples per resolution, high -> low
 
 

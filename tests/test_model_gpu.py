@@ -72,6 +72,19 @@ def test_bf16_close_to_oracle(name):
     assert all(e <= b for e, b in zip(errs, bar["fwd"])) and agg <= bar["grad_agg"]
 
 
+def test_lm_head_bf16():
+    """num_lm_head_layers > 0 under bf16 autocast (the fp32 run is held to the real reference's golden by
+    test_fp32_matches_oracle_and_golden[mini_unet_lmhead*]): same order of error as the other bf16 cases"""
+    outs, grads = hip_run("mini_unet_lmhead", torch.bfloat16)
+    o_ref, g_ref = PC.oracle_run("mini_unet_lmhead")
+    assert O.rel_l2(outs[0], o_ref[0]) < 1.5 * REF_BF16["mini_unet_masked"]["fwd"][0]
+    head = [k for k in g_ref if k.startswith("lm_head.")]
+    assert head and all(torch.isfinite(grads[k]).all() for k in head)
+    num = sum(float((grads[k].double().cpu() - g_ref[k].double()).pow(2).sum()) for k in head)
+    den = sum(float(g_ref[k].double().pow(2).sum()) for k in head)
+    assert (num / den) ** 0.5 < 5e-2
+
+
 def test_forward_is_deterministic():
     a, _ = hip_run("mini_unet", torch.float32, with_grad=False)
     b, _ = hip_run("mini_unet", torch.float32, with_grad=False)
