@@ -190,8 +190,8 @@ def timed_steps(step, sample, warmup, steps, sync):
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if os.environ.get("BENCH_STEP_TIMES") else None
     # The cyclic garbage collector stays out of the timed region (collected before, re-enabled after; reference counting
     # frees the step's tensors as always): a generation-2 pass over the module / autograd object graph is a 100+ ms host
-    # stall at a random step (the suspected cause of two of this round's twelve runs reading 107-108 ms where the same box
-    # then gave 93-94).
+    # stall at a random step.  (It was suspected of the occasional first run on a box reading 107-112 ms where the next
+    # process reads 93-95; those still occur with the collector off.)
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
