@@ -2072,16 +2072,17 @@ static bool conv_bl_ok(const ConvArgs& a) {
 static int g_split_fill = 80;   // development knob 6
 static int g_no_direct = 0;     // development knob 7: 1 = narrow 3x3 convolutions back on the implicit-GEMM kernel
 static int g_no_wgrad_direct = 0;   // development knob 8 (mdm_dev_set_knob): 1 = no wgrad_direct_kernel (split GEMM for the narrow weight gradients too)
+static int g_split_minkt = 6, g_split_minsave = 16;   // development knobs 9, 10
 static int conv_ksplit(int M, int Cout, int K, int dtype) {
   if (dtype != DT_BF16 || K % 64 != 0 || Cout % 8 != 0 || Cout <= 64) return 1;
   const int fill = g_split_fill;   // development knob 6 (mdm_dev_set_knob), default 80
   const long tiles = (long)((M + 127) / 128) * ((Cout + 127) / 128);
   const int nt = K / 64, cus = device_cus();
-  if (tiles * 100 > (long)fill * 2 * cus || nt < 12) return 1;
+  if (tiles * 100 > (long)fill * 2 * cus || nt < 2 * g_split_minkt) return 1;
   long sp = (2L * cus) / tiles;
-  if (sp > nt / 6) sp = nt / 6;
+  if (sp > nt / g_split_minkt) sp = nt / g_split_minkt;
   if (sp > 16) sp = 16;
-  if (sp < 2 || nt - (nt + sp - 1) / sp < 16) return 1;
+  if (sp < 2 || nt - (nt + sp - 1) / sp < g_split_minsave) return 1;
   return (int)sp;
 }
 
@@ -2595,8 +2596,10 @@ extern "C" int mdm_linear_grouped(const void* const* x, const void* const* w_pac
 }
 
 extern "C" int mdm_dev_set_knob(int idx, int value) {
-  MDM_CHECK_ARG(idx >= 0 && idx < 9);
+  MDM_CHECK_ARG(idx >= 0 && idx < 11);
   if (idx == 8) { g_no_wgrad_direct = value; return 0; }
+  if (idx == 9) { g_split_minkt = value > 0 ? value : 6; return 0; }
+  if (idx == 10) { g_split_minsave = value > 0 ? value : 16; return 0; }
   if (idx == 3) { g_force_x = value; return 0; }
   if (idx == 6) { g_split_fill = value > 0 ? value : 80; return 0; }
   if (idx == 7) { g_no_direct = value; return 0; }
