@@ -23,7 +23,9 @@ int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype);
  *   6  tile-fill percentage below which a forward GEMM may split its reduction (default 80; 25 = the sampling-only rule)
  *   7  1 = the narrow 3x3 convolutions of the nested models go back to the implicit-GEMM kernel (no conv3x3_direct_kernel)
  *   8  1 = the narrow weight gradients (64 output channels, >= 262144 pixels) go back to the split GEMM (no wgrad_direct_kernel)
- *   9  forward split-K: minimum k-tiles per range (default 6);  10: minimum k-tiles of serial walk a split must save (default 16) */
+ *   9  forward split-K: minimum k-tiles per range (default 6);  10: minimum k-tiles of serial walk a split must save (default 16)
+ *  11  1 = no 4-stage instantiations of conv_gemm_bl_kernel<128, 128> for under-filled grids (small-batch sampling)
+ *  12  forward split-K: blocks per CU a split aims for (0 = by problem size: 1 for M <= 2048, else 2) */
 int mdm_dev_set_knob(int idx, int value);
 /* attention backward kernel choice: 0 = by shape, 1 = always the split (dQ + dK/dV) kernels, 2 = the one-block-per-head
  * kernel whenever the shape allows (tests) */

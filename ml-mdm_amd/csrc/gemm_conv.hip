@@ -497,7 +497,10 @@ struct NoConvGroup {};
 // from dy[b] and dy[b + 1], so over the 2x2-blocked dx (4 Cin channels per block) it is a 2x2 stride-1 correlation.
 // GN: the epilogue also normalises the output (ConvArgs::gn_*; its own instantiation, so the extra registers of that
 // epilogue do not touch the other kernels' allocation).
-template <int BM, int BN, int WM, int WN, int MODE, bool GROUPED = false, bool SPLITK = false, bool SEL4 = false, bool GN = false>
+// NSTG: LDS stages of the k-loop (2 in every training instantiation; 4 for the under-filled grids of small-batch sampling,
+// one block per CU: there a k-tile is 0.25 us of MFMA work behind a ~1.3 us DMA round trip, and with two stages every
+// k-tile waits for its own fetch -- with four, three fetches are in flight and the loop runs at the DMA's throughput).
+template <int BM, int BN, int WM, int WN, int MODE, bool GROUPED = false, bool SPLITK = false, bool SEL4 = false, bool GN = false, int NSTG = 2>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs p, std::conditional_t<GROUPED, ConvGroup, NoConvGroup> gr) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type has no host-side counterpart: the host pass only needs the stub
   using T = bf16;
@@ -648,6 +651,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
   {                                                                                                         \
     MDM_TILE_STATE(1);                                                                                      \
     _Pragma("unroll") for (int q = 0; q < AJ + BJ; ++q) { MDM_DMA_PIECE(smem + STAGE, q); }                 \
+  }                                                                                                         \
+  if constexpr (NSTG > 2) {                                                                                 \
+    {                                                                                                       \
+      MDM_TILE_STATE(2);                                                                                    \
+      _Pragma("unroll") for (int q = 0; q < AJ + BJ; ++q) { MDM_DMA_PIECE(smem + 2 * STAGE, q); }           \
+    }                                                                                                       \
+    {                                                                                                       \
+      MDM_TILE_STATE(3);                                                                                    \
+      _Pragma("unroll") for (int q = 0; q < AJ + BJ; ++q) { MDM_DMA_PIECE(smem + 3 * STAGE, q); }           \
+    }                                                                                                       \
   }
 
   int tile = b_in_group;
@@ -659,7 +672,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's first k-tiles (and the previous tile's stores)
+    // this tile's first k-tile (and the previous tile's stores, which are older); with NSTG > 2 the later prologue
+    // fetches stay in flight: every k-tile is AJ + BJ LDS-DMA instructions per wave, and vmcnt retires in order
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (AJ + BJ) + (NSTG > 2 ? AJ + BJ : 0)) : "memory");
     __syncthreads();
     Frag<T> af[MT], b0[NT], b1[NT];
 #pragma unroll
@@ -669,7 +684,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
     constexpr int DMA_PER_ROW = (AJ + BJ + MT - 1) / MT;
     const int kt_end = SPLITK ? nloc : ntiles;
     for (int kt = 0; kt < kt_end; ++kt) {
-      const char* As = smem + (kt & 1) * STAGE;
+      const char* As = smem + (kt % NSTG) * STAGE;
       const char* Bs = As + A_BYTES;
       // ---- phase A
 #pragma unroll
@@ -684,14 +699,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
       sched_rows<NT, 0>(std::make_integer_sequence<int, MT>{});
       __builtin_amdgcn_sched_barrier(0);
       // hipcc does not count the loop-carried LDS-DMA of the previous phase B at this barrier: retire it explicitly
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (tile kt + 1 must have landed; tiles kt + 2 .. kt + NSTG - 1 may still be in flight)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (AJ + BJ)) : "memory");
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase B
-      const char* An = smem + ((kt + 1) & 1) * STAGE;
+      const char* An = smem + ((kt + 1) % NSTG) * STAGE;
       const char* Bn = An + A_BYTES;
-      char* dst = smem + (kt & 1) * STAGE;
-      MDM_TILE_STATE(kt + 2);
+      char* dst = smem + (kt % NSTG) * STAGE;
+      MDM_TILE_STATE(kt + NSTG);
 #pragma unroll
       for (int j = 0; j < NT; ++j) load_frag<T>(b0[j], Bn, wn * TN + j * 16 + l16, 0, quad);
 #pragma unroll
@@ -736,7 +752,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
           MDM_TILE_PROLOGUE();
         }
       };
-      conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE, decltype(prefetch_next), GN>(pe, acc, smem, cur_m0, cur_n0, prefetch_next);
+      conv_epilogue<T, BM, BN, WM, WN, NSTG * STAGE, decltype(prefetch_next), GN>(pe, acc, smem, cur_m0, cur_n0, prefetch_next);
     }
     if (next >= tiles_total) break;
     tile = next;
@@ -1989,6 +2005,7 @@ __global__ __launch_bounds__(256) void upconv_bfold_kernel(const float* __restri
   db[co] = accumulate ? db[co] + v : v;
 }
 
+static int g_no_deep_pipe = 0;      // development knob 11: 1 = no 4-stage instantiations for under-filled grids
 static thread_local char g_last_gemm[96] = "";
 extern "C" const char* mdm_last_gemm_kernel(void) { return g_last_gemm; }
 #define MDM_NOTE_KERNEL(...) snprintf(g_last_gemm, sizeof(g_last_gemm), __VA_ARGS__)
@@ -2009,6 +2026,16 @@ static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
   auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE>;
   ensure_dynamic_lds(kern, smem);
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+  if constexpr (BM == 128 && BN == 128) {
+    // under-filled grid (sampling at batch 1-4): one block per CU, four LDS stages (see the kernel's NSTG note)
+    if (tiles <= device_cus() && !g_no_deep_pipe) {
+      auto kern4 = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE, false, false, false, false, 4>;
+      ensure_dynamic_lds(kern4, 2 * smem);
+      hipLaunchKernelGGL(kern4, dim3(tiles), dim3(WM * WN * 64), 2 * smem, st, a, NoConvGroup{});
+      MDM_NOTE_KERNEL("conv_gemm_bl_kernel<%d, %d, %d, %d, %d, 4 stages>", BM, BN, WM, WN, MODE);
+      MDM_LAUNCH_STATUS();
+    }
+  }
   const int resident = device_cus() * (WM * WN == 4 ? 2 : 1);   // persistent blocks: one (8 waves) or two (4 waves) per CU
   hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a, NoConvGroup{});
   MDM_NOTE_KERNEL("conv_gemm_bl_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, MODE);
@@ -2073,13 +2100,18 @@ static int g_split_fill = 80;   // development knob 6
 static int g_no_direct = 0;     // development knob 7: 1 = narrow 3x3 convolutions back on the implicit-GEMM kernel
 static int g_no_wgrad_direct = 0;   // development knob 8 (mdm_dev_set_knob): 1 = no wgrad_direct_kernel (split GEMM for the narrow weight gradients too)
 static int g_split_minkt = 6, g_split_minsave = 16;   // development knobs 9, 10
+static int g_split_per_cu = 0;                        // development knob 12: blocks per CU a split aims for (0 = by M, below)
 static int conv_ksplit(int M, int Cout, int K, int dtype) {
   if (dtype != DT_BF16 || K % 64 != 0 || Cout % 8 != 0 || Cout <= 64) return 1;
   const int fill = g_split_fill;   // development knob 6 (mdm_dev_set_knob), default 80
   const long tiles = (long)((M + 127) / 128) * ((Cout + 127) / 128);
   const int nt = K / 64, cus = device_cus();
   if (tiles * 100 > (long)fill * 2 * cus || nt < 2 * g_split_minkt) return 1;
-  long sp = (2L * cus) / tiles;
+  // blocks per CU a split aims for: two 2-stage blocks for the training shapes (M = 4096 of the nested models' inner U-Net),
+  // ONE 4-stage block for the sampling shapes (M <= 2048: 5.98 -> 5.84 ms per graphed UNet-64 iteration at batch 4,
+  // 20.8 -> 20.4 nested-1024; the nested-256 train step is indifferent, 59.4 vs 59.4)
+  const int per_cu = g_split_per_cu ? g_split_per_cu : (M <= 2048 ? 1 : 2);
+  long sp = ((long)per_cu * cus) / tiles;
   if (sp > nt / g_split_minkt) sp = nt / g_split_minkt;
   if (sp > 16) sp = 16;
   if (sp < 2 || nt - (nt + sp - 1) / sp < g_split_minsave) return 1;
@@ -2105,6 +2137,11 @@ static int launch_conv_bl_splitk(ConvArgs a, int splits, float* ws, hipStream_t 
   a.part = ws;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN) * a.ksplit;
   const int resident = device_cus() * 2;
+  if (tiles <= device_cus() && !g_no_deep_pipe) {   // one block per CU: four LDS stages
+    auto kern4 = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE, false, true, false, false, 4>;
+    ensure_dynamic_lds(kern4, 2 * smem);
+    hipLaunchKernelGGL(kern4, dim3(tiles), dim3(WM * WN * 64), 2 * smem, st, a, NoConvGroup{});
+  } else
   hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a, NoConvGroup{});
   const size_t mc = (size_t)a.M * a.Cout;
   hipLaunchKernelGGL(splitk_epilogue_kernel<bf16>, dim3((unsigned)((mc / 4 + 255) / 256)), dim3(256), 0, st, ws, a.ksplit, mc,
@@ -2596,7 +2633,9 @@ extern "C" int mdm_linear_grouped(const void* const* x, const void* const* w_pac
 }
 
 extern "C" int mdm_dev_set_knob(int idx, int value) {
-  MDM_CHECK_ARG(idx >= 0 && idx < 11);
+  MDM_CHECK_ARG(idx >= 0 && idx < 13);
+  if (idx == 12) { g_split_per_cu = value > 0 ? value : 0; return 0; }
+  if (idx == 11) { g_no_deep_pipe = value; return 0; }
   if (idx == 8) { g_no_wgrad_direct = value; return 0; }
   if (idx == 9) { g_split_minkt = value > 0 ? value : 6; return 0; }
   if (idx == 10) { g_split_minsave = value > 0 ? value : 16; return 0; }

@@ -142,6 +142,10 @@ def _apply_dev_env(handle):
         handle.mdm_dev_set_knob(9, int(os.environ["MDM_HIP_SPLIT_MINKT"]))
     if os.environ.get("MDM_HIP_SPLIT_MINSAVE"):
         handle.mdm_dev_set_knob(10, int(os.environ["MDM_HIP_SPLIT_MINSAVE"]))
+    if os.environ.get("MDM_HIP_SPLIT_PER_CU"):
+        handle.mdm_dev_set_knob(12, int(os.environ["MDM_HIP_SPLIT_PER_CU"]))
+    if os.environ.get("MDM_HIP_DEEP_PIPE") == "0":   # no 4-stage GEMM instantiations for under-filled grids
+        handle.mdm_dev_set_knob(11, 1)
     if os.environ.get("MDM_HIP_WGRAD_DIRECT") == "0":   # narrow weight gradients by the split GEMM
         handle.mdm_dev_set_knob(8, 1)
     if os.environ.get("MDM_HIP_GEMM_X") == "2":   # conv_gemm_x_kernel whenever the problem allows (default: never)
