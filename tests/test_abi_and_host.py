@@ -192,7 +192,8 @@ def test_no_mfma_result_is_read_back_early_on_a_branch_edge():
     """tools/mfma_hazard_scan.py over the ISA of the two MFMA-bearing sources: no read of an MFMA's destination registers
     within 6 wait states on ANY path, taken branch edges included.  ROCm 7.2's hazard recognizer missed exactly that in
     conv3x3_direct_kernel<64, 64, 8, 32, 4> (stale accumulators, caught by the GPU parity test; the kernel now fences its
-    k-loop from its epilogue) -- this keeps a recompile from reintroducing it silently.  Cross-compiles, no GPU needed."""
+    k-loop from its epilogue) -- this keeps a recompile from reintroducing it silently.  The same pass checks that no kernel
+    of the two sources spills more than 24 vector registers (today's worst: 15).  Cross-compiles, no GPU needed."""
     import importlib.util
     import shutil
 

@@ -4,7 +4,8 @@ LDS / global store) with too few wait states when the read sits on the TAKEN edg
 recognizer covered the fall-through path only (conv3x3_direct_kernel<64, 64, 8, 32, 4>).
 Walks every path of up to 10 wait states after each v_mfma (following branches) and reports reads of its destination
 registers that come earlier than `MIN_WS` (the compiler itself leaves 11 in straight-line code).  CPU-only:
-   python tools/mfma_hazard_scan.py            # compiles csrc/gemm_conv.hip and attention.hip to ISA, exits 1 on a finding"""
+   python tools/mfma_hazard_scan.py            # compiles csrc/gemm_conv.hip and attention.hip to ISA, exits 1 on a finding
+Also checks, on the same ISA, that no kernel spills more than SPILL_CAP vector registers."""
 import collections
 import os
 import re
@@ -14,6 +15,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MIN_WS = 6
+SPILL_CAP = 24   # spilled VGPRs tolerated per kernel (today's worst: 15, a tap-selecting 8-wave GEMM tile)
 
 
 def regs(tok):
@@ -86,6 +88,17 @@ def main():
             for (name, ws), cnt in sorted(collections.Counter((f[0], f[1]) for f in early).items()):
                 print("   %d wait states, x%d: %s" % (ws, cnt, name[:100]))
             bad += len(early)
+            # second static guard on the same ISA: spilled vector registers.  The hot kernels run at 0-15 (the 8-wave GEMM
+            # tiles sit at their 256-register limit); a recompile that pushes any kernel past SPILL_CAP is a scratch-memory
+            # round trip inside an MFMA loop -- the kind of regression a parity test does not see.
+            meta = open(out).read()
+            spills = [(int(m.group(2)), m.group(1)) for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", meta)]
+            worst = sorted((sp for sp in spills if sp[0] > 0), reverse=True)
+            print("   kernels with spilled VGPRs: %d of %d, worst %s" % (len(worst), len(spills), ["%d %s" % (n, k[:60]) for n, k in worst[:3]]))
+            over = [sp for sp in worst if sp[0] > SPILL_CAP]
+            for n, k in over:
+                print("   OVER THE SPILL CAP (%d): %d %s" % (SPILL_CAP, n, k))
+            bad += len(over)
     return 1 if bad else 0
 
 
