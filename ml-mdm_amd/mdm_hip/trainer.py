@@ -61,6 +61,7 @@ class FusedState:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)   # optimizer step number, on the device
         self.reducer.rebind()
         self.async_wgrad = async_wgrad
+        self._host_vals = {}     # name -> (pinned host scalar, event): device scalars the host reads AFTER it has queued more work
         self.activate()
 
     def activate(self):
@@ -80,9 +81,30 @@ class FusedState:
         ops.join_side_stream()
         self.reducer.finish()
 
-    def optimizer_step(self, lr, betas, eps, weight_decay, clip_norm, ema_decay, dtype):
+    def post_scalar(self, name, value):
+        """queue an asynchronous device -> pinned-host copy of a one-element tensor behind what the current stream holds NOW
+        (and an event); `read_scalar(name)` later waits for exactly that point of the stream -- not for the kernels the host
+        has queued since.  This is what lets train_batch queue backward + optimizer tail before it looks at the loss."""
+        ent = self._host_vals.get(name)
+        if ent is None:
+            ent = (torch.empty(1, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+            self._host_vals[name] = ent
+        ent[0].copy_(value.detach().reshape(1), non_blocking=True)
+        ent[1].record()
+
+    def read_scalar(self, name):
+        buf, ev = self._host_vals[name]
+        ev.synchronize()
+        return float(buf[0])
+
+    def optimizer_step(self, lr, betas, eps, weight_decay, clip_norm, ema_decay, dtype, loss=None):
         """clip + AdamW + EMA + zero-grad over the arenas (two launches) and the re-pack of the kernel-layout weights.
-        A non-finite gradient norm skips the update, clears the gradients and does not advance the step number."""
+        A non-finite gradient norm skips the update, clears the gradients and does not advance the step number.
+        `loss` (a device scalar, one rank only): a NaN loss makes the norm NaN whatever the gradients turned out to be --
+        the reference's "NaN loss => no step" (trainer.py:38-41, 64-69) decided on the device, without the host."""
+        if loss is not None and self.reducer.world == 1:
+            # (into the arena, ahead of the norm: mdm_sumsq is also what advances the device-side step number)
+            self.reducer.flat[:1].add_(loss.detach().float().reshape(1) * 0.0)   # NaN * 0 = NaN, finite * 0 = 0
         ops.sumsq(self.reducer.flat, out=self.gnorm_sq, step_counter=self.step_dev)
         ops.adamw_ema_step(self.flat_p, self.reducer.flat, self.m, self.v, self.flat_ema, self.gnorm_sq, lr, betas[0], betas[1],
                            eps, weight_decay, 0, clip_norm, ema_decay, zero_grad=True, step_dev=self.step_dev)
@@ -216,25 +238,22 @@ def train_batch(model, sample, optimizer, scheduler, logger, args, grad_scaler=N
                            "the model's device, or wrap the model in torch.nn.parallel.DistributedDataParallel instead."
                            % getattr(optimizer, "_mdm_fused_reason", "?"))
     fp16 = bool(getattr(args, "fp16", False))
-    # several ranks in a synchronised fused step: a NaN loss on ONE rank must not change that rank's host-side sequence
-    # (scheduler.step(), EMA warm-up counter) -- every rank runs backward and the common tail, the update is skipped on
-    # the device by all of them (the reduced gradient norm is not finite), and the NaN is reported through loss_val
-    lockstep = st is not None and st.reducer.world > 1 and not accumulate_gradient
     dev_type = "cuda" if next(_vision_model(model).parameters()).is_cuda else "cpu"
-    if st is not None and ops._grad_sink is not st.reducer:
-        st.activate()   # another FusedState (a second model in the same process) was used in between
-
+    if st is not None:
+        return _train_batch_fused(st, model, sample, optimizer, scheduler, logger, args, accumulate_gradient,
+                                  num_grad_accumulations, ema_model, loss_factor, lr, fp16)
+    # ---- plain path: the reference's sequence with torch's own pieces ------------------------------------------------------
     if fp16:
         with torch.autocast(dev_type, dtype=torch.bfloat16):
             losses, times, x_t, means, targets, weights = model.get_loss(sample)
             loss = _loss_of(losses, weights) * loss_factor
             loss_val = loss.item()
-            if math.isnan(loss_val) and not lockstep:
-                _skip_step(st, optimizer, loss, accumulate_gradient, args, fp16)
+            if math.isnan(loss_val):
+                optimizer.zero_grad()
                 return loss_val, losses, times, x_t, means, targets
             if num_grad_accumulations != 1:
                 loss = loss / num_grad_accumulations
-        if st is None and grad_scaler is not None:
+        if grad_scaler is not None:
             grad_scaler.scale(loss).backward()
         else:
             loss.backward()
@@ -242,63 +261,120 @@ def train_batch(model, sample, optimizer, scheduler, logger, args, grad_scaler=N
         losses, times, x_t, means, targets, weights = model.get_loss(sample)
         loss = _loss_of(losses, weights)
         loss_val = loss.item()
-        if math.isnan(loss_val) and not lockstep:
-            _skip_step(st, optimizer, loss, accumulate_gradient, args, fp16)
-            if st is None:
-                optimizer.step()
+        if math.isnan(loss_val):
+            optimizer.zero_grad()
+            optimizer.step()
             scheduler.step()
             return loss_val, losses, times, x_t, means, targets
         loss.backward()   # (the reference divides by num_grad_accumulations only AFTER this, trainer.py:73-75: no effect)
 
-    if st is not None:
-        # also after an accumulation micro-step: nothing queued (grouped weight gradients, GroupNorm parameter rows) may
-        # cross into the next micro-step, where its ready() report would release a bucket before that step's own
-        # gradient is written; inside no_sync() the reducer's finish() joins nothing
-        st.finish_backward()
     if not accumulate_gradient:
         clip = float(getattr(args, "gradient_clip_norm", 2.0))
-        if st is not None:
-            grp = optimizer.param_groups[0]
-            decay = 0.0
-            if ema_model is not None:   # ModelEma.update (models/model_ema.py:25-34), warm-up included
-                decay = float(ema_model.counter >= ema_model.warmup_steps) * ema_model.decay
-                ema_model.counter += 1
-            st.optimizer_step(grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"], clip, decay,
-                              torch.bfloat16 if fp16 else torch.float32)
-            optimizer._opt_called = True   # the step happened (silences lr_scheduler's call-order warning)
+        core = getattr(model.model, "module", model.model)
+        if fp16 and grad_scaler is not None:
+            grad_scaler.unscale_(optimizer)
+            torch.nn.utils.clip_grad_norm_(model.model.parameters(), clip)
+            grad_scaler.step(optimizer)
+            grad_scaler.update()
         else:
-            core = getattr(model.model, "module", model.model)
-            if fp16 and grad_scaler is not None:
-                grad_scaler.unscale_(optimizer)
-                torch.nn.utils.clip_grad_norm_(model.model.parameters(), clip)
-                grad_scaler.step(optimizer)
-                grad_scaler.update()
-            else:
-                torch.nn.utils.clip_grad_norm_(model.model.parameters(), clip)
-                optimizer.step()
-            ops.invalidate_packed_weights()
-            if ema_model is not None:
-                ema_model.update(core.vision_model)
-
-    if logger is not None and not accumulate_gradient:
-        logger.add_scalar("train/Loss", loss_val)
-        logger.add_scalar("lr", lr)
-    if not accumulate_gradient:
-        if st is None:
-            optimizer.zero_grad()
+            torch.nn.utils.clip_grad_norm_(model.model.parameters(), clip)
+            optimizer.step()
+        ops.invalidate_packed_weights()
+        if ema_model is not None:
+            ema_model.update(core.vision_model)
+        if logger is not None:
+            logger.add_scalar("train/Loss", loss_val)
+            logger.add_scalar("lr", lr)
+        optimizer.zero_grad()
         scheduler.step()
     return loss_val, losses, times, x_t, means, targets
 
 
+# the loss is read AFTER backward and the optimizer tail are queued (0: where the reference reads it, before backward --
+# the host then cannot queue the backward until the forward has drained; A/B switch)
+_LATE_LOSS_READ = os.environ.get("MDM_HIP_EARLY_LOSS_SYNC", "0") != "1"
+
+
+def _train_batch_fused(st, model, sample, optimizer, scheduler, logger, args, accumulate_gradient, num_grad_accumulations,
+                       ema_model, loss_factor, lr, fp16):
+    """The fused path of `train_batch`.  Same observable sequence as the reference (trainer.py:27-96), but the host never
+    waits for the GPU in the middle of a step: the loss goes to pinned host memory by an asynchronous copy queued right
+    behind the forward, backward + clip + AdamW + EMA are queued, and only then does the host look at the value -- by then
+    the copy's event has long fired or fires while the GPU is busy with the backward.  What the reference decides on the
+    host before backward ("NaN loss: drop the gradients, take no step") is decided on the device for the optimizer tail (a
+    NaN loss poisons the gradient norm: no update, gradients cleared, step number kept) and replayed on the host afterwards
+    for the rest (no EMA-counter increment, no logging, scheduler as the reference's branch has it)."""
+    # several ranks in a synchronised step: a NaN loss on ONE rank must not change that rank's sequence of collectives --
+    # every rank runs backward and the common tail; the update is skipped on the device by all of them (the REDUCED
+    # gradient norm is not finite), and all of them learn it from that norm, so scheduler / EMA counter stay identical
+    lockstep = st.reducer.world > 1 and not accumulate_gradient
+    if ops._grad_sink is not st.reducer:
+        st.activate()   # another FusedState (a second model in the same process) was used in between
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=fp16):
+        losses, times, x_t, means, targets, weights = model.get_loss(sample)
+        loss = _loss_of(losses, weights)
+        if fp16:
+            loss = loss * loss_factor          # (the reference's fp32 branch has no loss_factor, trainer.py:58-63)
+        if _LATE_LOSS_READ:
+            st.post_scalar("loss", loss)
+            loss_val = None
+        else:
+            loss_val = loss.item()
+            if math.isnan(loss_val) and not lockstep:
+                return _fused_nan_return(st, optimizer, scheduler, fp16, loss_val, losses, times, x_t, means, targets, True)
+        if fp16 and num_grad_accumulations != 1:
+            loss = loss / num_grad_accumulations
+    loss.backward()   # (fp32: the reference divides by num_grad_accumulations only AFTER this, trainer.py:73-75: no effect)
+    # also after an accumulation micro-step: nothing queued (grouped weight gradients, GroupNorm parameter rows) may cross
+    # into the next micro-step, where its ready() report would release a bucket before that step's own gradient is
+    # written; inside no_sync() the reducer's finish() joins nothing
+    st.finish_backward()
+    if not accumulate_gradient:
+        grp = optimizer.param_groups[0]
+        decay = 0.0
+        if ema_model is not None:   # ModelEma.update (models/model_ema.py:25-34), warm-up included
+            decay = float(ema_model.counter >= ema_model.warmup_steps) * ema_model.decay
+        st.optimizer_step(grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"], float(getattr(args, "gradient_clip_norm", 2.0)),
+                          decay, torch.bfloat16 if fp16 else torch.float32, loss=loss)
+        optimizer._opt_called = True   # the step happened (silences lr_scheduler's call-order warning)
+        if lockstep:
+            st.post_scalar("gnorm_sq", st.gnorm_sq)
+    if loss_val is None:
+        loss_val = st.read_scalar("loss")
+    if lockstep:
+        # identical on every rank (the norm of the all-reduced gradient): what a NaN anywhere did to this step
+        if not math.isfinite(st.read_scalar("gnorm_sq")):
+            return _fused_nan_return(st, optimizer, scheduler, fp16, loss_val, losses, times, x_t, means, targets, False)
+    elif math.isnan(loss_val):
+        # the device has skipped the update and cleared the arena (final micro-step), or the arena holds this micro-step's
+        # NaNs on top of the earlier micro-steps' gradients, which the reference drops too (trainer.py:39, 66)
+        return _fused_nan_return(st, optimizer, scheduler, fp16, loss_val, losses, times, x_t, means, targets, accumulate_gradient)
+    if not accumulate_gradient:
+        if ema_model is not None:
+            ema_model.counter += 1
+        if logger is not None:
+            logger.add_scalar("train/Loss", loss_val)
+            logger.add_scalar("lr", lr)
+        scheduler.step()
+    return loss_val, losses, times, x_t, means, targets
+
+
+def _fused_nan_return(st, optimizer, scheduler, fp16, loss_val, losses, times, x_t, means, targets, clear):
+    """the reference's early return on a NaN loss (trainer.py:38-41 bf16: zero_grad, return; 64-69 fp32: zero_grad, a
+    no-op optimizer.step(), scheduler.step(), return)"""
+    if clear:
+        _skip_step(st, optimizer, None, False, None, fp16)
+    if not fp16:
+        scheduler.step()
+    return loss_val, losses, times, x_t, means, targets
+
+
+
 def _skip_step(st, optimizer, loss, accumulate_gradient, args, fp16):
-    """NaN loss: drop the gradients accumulated so far and take no step (reference trainer.py:38-41, 64-69).  Only
-    reached where no other rank depends on this one's sequence (one rank, the plain path, or an accumulation micro-step
-    under no_sync()); in a synchronised multi-rank fused step train_batch does NOT return early -- with the reference's
-    per-rank early return the other ranks wait for bucket all-reduces that never come, and a rank that skips
-    scheduler.step() / the EMA counter trains on another learning rate from then on."""
-    if st is None:
-        optimizer.zero_grad()
-        return
+    """NaN loss on the fused path: drop the gradients accumulated so far (reference trainer.py:39, 66).  Only reached where
+    no other rank depends on this one's sequence (one rank, or an accumulation micro-step under no_sync()); in a
+    synchronised multi-rank step train_batch does NOT return before the collectives -- with the reference's per-rank early
+    return the other ranks wait for bucket all-reduces that never come."""
     st.finish_backward()    # nothing may still be adding into the arena
     st.reducer.zero_grad()
 
@@ -390,16 +466,17 @@ class TrainStep:
             losses, times, x_t, means, targets, weights = self.pipeline.get_loss(sample, **loss_kw)
             loss = _loss_of(losses, weights)
         if self.fused:
-            # The loss is read where the reference reads it (trainer.py:37) -- by then the host has queued the whole
-            # forward, and it queues the next step's forward while this step's backward runs -- but nothing branches on
-            # it: a NaN / inf loss gives a non-finite gradient norm, and the fused optimizer then skips the update,
-            # clears the gradients and does not advance its (device-side) step number.  Same outcome as the reference's
-            # early return (trainer.py:38-41), identical on every rank without a collective.
-            loss_val = loss.item()
+            # Nothing branches on the loss before backward: a NaN / inf loss gives a non-finite gradient norm, and the fused
+            # optimizer then skips the update, clears the gradients and does not advance its (device-side) step number --
+            # same outcome as the reference's early return (trainer.py:38-41), identical on every rank without a
+            # collective.  The value itself travels to pinned host memory behind the forward and is read once backward
+            # and the optimizer tail are queued: the host never waits for the GPU in the middle of a step.
+            self.state.post_scalar("loss", loss)
             loss.backward()
             self.state.finish_backward()
             self.state.optimizer_step(self.lr, self.betas, self.eps, self.weight_decay, self.clip_norm, self.ema_decay,
-                                      torch.bfloat16 if self.bf16 else torch.float32)
+                                      torch.bfloat16 if self.bf16 else torch.float32, loss=loss)
+            loss_val = self.state.read_scalar("loss")
             self.steps += 1 if math.isfinite(loss_val) else 0
             return loss_val
         loss_val = loss.item()  # the reference syncs here every step (trainer.py:37)
