@@ -194,16 +194,18 @@ def timed_steps(step, sample, warmup, steps, sync):
     # process reads 93-95; those still occur with the collector off.)
     gc.collect()
     gc.disable()
-    t0 = time.perf_counter()
-    if evs:
-        evs[0].record()
-    for i in range(steps):
-        step(sample)
+    try:
+        t0 = time.perf_counter()
         if evs:
-            evs[i + 1].record()
-    sync()
-    dt = time.perf_counter() - t0
-    gc.enable()
+            evs[0].record()
+        for i in range(steps):
+            step(sample)
+            if evs:
+                evs[i + 1].record()
+        sync()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()   # (an exception in a timed step -- an OOM caught by an outer leg -- must not leave the collector off)
     if evs:
         print("per-step ms: " + " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(steps)), file=sys.stderr)
     return dt

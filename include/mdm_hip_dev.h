@@ -27,8 +27,9 @@ int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype);
  *  11  1 = no 4-stage instantiations of conv_gemm_bl_kernel<128, 128> for under-filled grids (small-batch sampling)
  *  12  forward split-K: blocks per CU a split aims for (0 = by problem size: 1 for M <= 2048, else 2) */
 int mdm_dev_set_knob(int idx, int value);
-/* attention backward kernel choice: 0 = by shape, 1 = always the split (dQ + dK/dV) kernels, 2 = the one-block-per-head
- * kernel whenever the shape allows (tests) */
+/* attention backward kernel choice: 0 = by shape, 1 = always the split (dQ + dK/dV) kernels on 16x16x32 MFMAs, 2 = the
+ * one-block-per-head kernel whenever the shape allows (tests), 3 = as 2 but the 16x16x32 one, 4 = the streaming kernels on
+ * 32x32x16 MFMAs (csrc/attn32.hpp) whenever the shape allows */
 int mdm_dev_set_attn_bwd(int mode);
 
 #ifdef __cplusplus

@@ -1227,6 +1227,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
 
 }  // namespace mdm
 
+#include "attn32.hpp"   // the backward on v_mfma_f32_32x32x16_bf16 (a wave owns 32 keys / queries)
+
 using namespace mdm;
 
 template <typename T, int D, bool SPLIT = false>
@@ -1260,7 +1262,7 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
 // drives the experiment -- no environment lookups inside the boundary's entry points
 static int g_attn_bwd_mode = 0;
 extern "C" int mdm_dev_set_attn_bwd(int mode) {
-  if (mode < 0 || mode > 2) return -1;
+  if (mode < 0 || mode > 4) return -1;
   g_attn_bwd_mode = mode;
   return 0;
 }
@@ -1283,10 +1285,31 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
   a.dkc = dkc; a.dvc = dvc; a.dkc_bs = dc_bs; a.dkc_rs = dc_rs;
   if constexpr (sizeof(T) == 2) {
     // short sequences: one block per (batch, head), operands LDS-resident (attn_bwd_small_kernel)
-    // development knob mdm_dev_set_attn_bwd (include/mdm_hip_dev.h): 1 = "split" (never), 2 = "small" (whenever the shape
-    // allows; the tests) override the choice below; 0 in the product
-    const bool split_only = g_attn_bwd_mode == 1;
-    const bool force_small = g_attn_bwd_mode == 2;
+    // development knob mdm_dev_set_attn_bwd (include/mdm_hip_dev.h), 0 in the product: 1 = "split" (the two streaming
+    // kernels on 16x16x32 MFMAs, always), 2 = "small" (one block per head whenever the shape allows; the tests),
+    // 3 = "small16" (as 2, but the round-3 kernel on 16x16x32 MFMAs), 4 = "stream32" (the two streaming kernels of
+    // attn32.hpp whenever the shape allows)
+    const bool split_only = g_attn_bwd_mode == 1 || g_attn_bwd_mode == 4;
+    const bool force_small = g_attn_bwd_mode == 2 || g_attn_bwd_mode == 3;
+    if constexpr (D == 64 || D == 96) {
+      // a wave owns 32 keys / queries (attn32.hpp): one pass over the resident tiles for all 256 rows of the level
+      if (a.L <= 256 && (!a.kc || a.S <= 32) && (a.B * a.H >= device_cus() || force_small) && !split_only && g_attn_bwd_mode != 3) {
+        constexpr int smem32 = attn_bwd_small32_lds<D>();
+        ensure_dynamic_lds(attn_bwd_small32_kernel<D>, smem32);
+        hipLaunchKernelGGL((attn_bwd_small32_kernel<D>), dim3(a.B * a.H), dim3(512), smem32, st, a);
+        MDM_LAUNCH_STATUS();
+      }
+      // long sequences (the 32x32 level: L = 1024): the same tile steps, keys / queries streamed through LDS
+      if (((a.L > 256 && g_attn_bwd_mode == 0) || g_attn_bwd_mode == 4) && (!a.kc || a.S <= 32)) {
+        constexpr int smem_dq = attn_bwd_dq32_lds<D>(), smem_dkv = attn_bwd_dkv32_lds<D>();
+        ensure_dynamic_lds(attn_bwd_dq32_kernel<D>, smem_dq);
+        ensure_dynamic_lds(attn_bwd_dkv32_kernel<D>, smem_dkv);
+        const int nb = (a.L + 255) / 256;
+        hipLaunchKernelGGL((attn_bwd_dq32_kernel<D>), dim3(nb, a.B * a.H), dim3(512), smem_dq, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkv32_kernel<D>), dim3(nb + (a.kc ? 1 : 0), a.B * a.H), dim3(512), smem_dkv, st, a);
+        MDM_LAUNCH_STATUS();
+      }
+    }
     // (one block per head: worth it once the heads fill the chip -- at batch 16 the 128 blocks of the 64x64 U-Net's
     // 16x16 level would leave half the CUs idle, and the streaming kernels' 4 + 5 blocks per head win)
     if (a.L <= 256 && (!a.kc || a.S <= 64) && (a.B * a.H >= device_cus() || force_small) && !split_only) {

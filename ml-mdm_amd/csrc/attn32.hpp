@@ -1,0 +1,742 @@
+// Attention backward on v_mfma_f32_32x32x16_bf16 (included by attention.hip; reference ml_mdm/models/unet.py:276-313).
+//
+// Why another set of kernels.  The 16x16x32 kernels of attention.hip give a wave 16 keys (or queries): at the 16x16 level
+// of the U-Net (L = 256, d = 96; 26 of 31 attention layers) the one-block-per-head backward walks the query tiles TWICE
+// for its 256 keys and the key tiles twice for its 256 queries, every MFMA reads a full 1 KB operand fragment from LDS for
+// 16 K FLOP, and the 128-byte-row tile image makes the transpose reads 2-way bank conflicted -- 160-190 TF (6-8 % of the
+// matrix peak).  Here a wave owns 32 rows:
+//   * 8 waves x 32 = all 256 keys (queries) of the level in ONE pass over the resident operand tiles;
+//   * a 32x32x16 MFMA does 32 K FLOP per 1 KB LDS fragment -- half the LDS bytes per FLOP;
+//   * the accumulator layout of S = Q K^T (lane <-> key, register r <-> query 8 (r >> 2) + 4 (lane >> 5) + (r & 3)) makes
+//     registers 8 s .. 8 s + 7 of P / dS, packed to bf16, the operand of reduction step s of dV^T += dO^T P, dK^T += Q^T dS
+//     as they are (no cross-lane movement); the matching operand is two ds_read_b64_tr_b16 per lane from the NATURAL
+//     [row][d] image (rows 16 s + 4 hi + i and 16 s + 8 + 4 hi + i).  Same for dQ^T += K^T dS^T with lane <-> query;
+//   * lse and delta enter as the INITIAL accumulators (C operand) of the S and dP products: S' = Q K^T - lse / scale,
+//     dP' = dO V^T - delta, so P = 2^(c2 S') and dS = P dP' -- one multiply and one v_exp per score, no subtracts;
+//   * the tile image is a plain [row][d] array (pitch 2 d bytes) whose 16-byte chunk index is XOR-ed with a function of the
+//     row chosen so that BOTH access patterns are bank-conflict free: ds_read_b128 of one chunk column by 16 rows of all
+//     residues mod 16, and the transpose read's 4 rows x 64 bytes per 32 lanes (A32::swz).
+//
+// Operand maps of v_mfma_f32_32x32x16_bf16 (D = A B + C; cdna guide section 3, and csrc/gemm_x.hpp which runs on them):
+//   A: lane l holds A[row = l & 31][k = 8 (l >> 5) + j], j = 0..7      B: lane l holds B[k = 8 (l >> 5) + j][col = l & 31]
+//   C / D: lane l, register r holds D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]
+#pragma once
+
+namespace mdm {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// natural [row][D] bf16 image with swizzled 16-byte chunks
+template <int D> struct A32 {
+  static_assert(D == 64 || D == 96, "A32: head dims 64 and 96");
+  static constexpr int PITCH = 2 * D;      // bytes per row
+  static constexpr int CPR = D / 8;        // 16-byte chunks per row
+  static constexpr int KS = D / 16;        // reduction steps of a product over d
+  static constexpr int NB = D / 32;        // 32-wide blocks across d
+  // chunk XOR of a row.  Conflict-free by construction for (a) 16 rows of all residues mod 16 reading the same logical
+  // chunk (ds_read_b128 lane groups), (b) rows 4 q .. 4 q + 3 x logical chunks 4 m .. 4 m + 3 (one half of a transpose read):
+  //   D = 96 (pitch 192 B: row r starts at 16-byte slot 12 r mod 16 = 4 (-r & 3)): XOR the low two chunk bits with
+  //           (r >> 2) & 3 -- rows of equal r & 3 differ there, rows of different r & 3 start in different 64-byte quarters;
+  //   D = 64 (pitch 128 B: two rows per 256 bytes): f = bit 1 of r -> chunk bit 2, bits 2-3 of r -> chunk bits 0-1.
+  static __device__ __forceinline__ int swz(int row) {
+    return D == 64 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
+  }
+  static __device__ __forceinline__ int off(int row, int chunk) { return row * PITCH + ((chunk ^ swz(row)) << 4); }
+};
+
+// Per-lane LDS byte offsets of the two fragment kinds inside an image, relative to a 32-row tile (tile t adds
+// 32 t PITCH: the swizzle only looks at row bits 1-3).
+//   b[s]      ds_read_b128 of row (lane & 31), elements 16 s + 8 hi .. + 7          (A or B operand of a product over d)
+//   tr[t][blk] ds_read_b64_tr_b16: rows 8 t + 4 hi + (i >> 2), columns 32 blk + 16 ((lane >> 4) & 1) + 4 (i & 3), i = lane & 15;
+//              reduction step s2 adds 16 s2 PITCH.  The lane receives column 32 blk + (lane & 31) of those four rows.
+template <int D> struct Frag32Off {
+  using G = A32<D>;
+  unsigned b[G::KS];
+  unsigned tr[2][G::NB];
+  __device__ __forceinline__ Frag32Off(int lane) {
+    const int n = lane & 31, hi = lane >> 5, i = lane & 15, cb = (lane >> 4) & 1;
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) b[s] = (unsigned)G::off(n, 2 * s + hi);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int blk = 0; blk < G::NB; ++blk) {
+        const int row = 8 * t + 4 * hi + (i >> 2);
+        const int col = 32 * blk + 16 * cb + 4 * (i & 3);
+        tr[t][blk] = (unsigned)(G::off(row, col >> 3) + ((col >> 2) & 1) * 8);
+      }
+  }
+};
+
+__device__ __forceinline__ bf16x8 lds_b128(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 lds_tr_pair(const char* p0, const char* p1) {
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p1));
+  s16x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
+  return bf16x8{(bf16)v[8 * s2 + 0], (bf16)v[8 * s2 + 1], (bf16)v[8 * s2 + 2], (bf16)v[8 * s2 + 3],
+                (bf16)v[8 * s2 + 4], (bf16)v[8 * s2 + 5], (bf16)v[8 * s2 + 6], (bf16)v[8 * s2 + 7]};
+}
+__device__ __forceinline__ f32x16 splat16(float v) {
+  return f32x16{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v};
+}
+__device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// rows [0, nrows) of a strided head view behind a buffer descriptor: rows past the end read as zeros
+struct RowSrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned row_bytes;
+  __device__ __forceinline__ RowSrc(const bf16* src, int rs, int nrows) {
+    row_bytes = (unsigned)rs * 2u;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(src), 0, (unsigned)nrows * row_bytes, 0x00020000);
+  }
+  __device__ __forceinline__ uint4 chunk(int row, int byte_in_row) const {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)row * row_bytes + (unsigned)byte_in_row, 0, 0);
+    return uint4{(unsigned)v[0], (unsigned)v[1], (unsigned)v[2], (unsigned)v[3]};
+  }
+  // the operand fragment of row `row`: elements 16 s + 8 hi .. + 7
+  __device__ __forceinline__ bf16x8 frag(int row, int s, int hi) const {
+    uint4 v = chunk(row, (16 * s + 8 * hi) * 2);
+    return *reinterpret_cast<bf16x8*>(&v);
+  }
+};
+
+// One 32-key tile for a wave that owns 32 queries (lane <-> query).  Kt / Vt: the tile's rows in a swizzled image; qf / gf:
+// the wave's Q / dO operand fragments; nl = -lse / scale, nd = -delta of the lane's query; `live`: bit k = key k of the
+// tile takes part (wave-uniform); dq: dQ^T accumulators (register r of block blk <-> channel 32 blk + 8 (r >> 2) + 4 hi + (r & 3)).
+template <int D>
+__device__ __forceinline__ void q_step32(const char* Kt, const char* Vt, const bf16x8 (&qf)[A32<D>::KS], const bf16x8 (&gf)[A32<D>::KS],
+                                         const float nl, const float nd, const unsigned live, const float c2, const int hi,
+                                         const Frag32Off<D>& fo, f32x16 (&dq)[A32<D>::NB]) {
+  using G = A32<D>;
+  f32x16 sc = splat16(nl), dp = splat16(nd);
+#pragma unroll
+  for (int s = 0; s < G::KS; ++s) {
+    sc = mma32(lds_b128(Kt + fo.b[s]), qf[s], sc);
+    dp = mma32(lds_b128(Vt + fo.b[s]), gf[s], dp);
+  }
+  if (live == 0xffffffffu) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r] * c2) * dp[r];
+  } else {
+    const unsigned lv = live >> (4 * hi);    // this lane's registers hold keys (r & 3) + 8 (r >> 2) + 4 hi
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = ((lv >> ((r & 3) + 8 * (r >> 2))) & 1u) ? __builtin_amdgcn_exp2f(sc[r] * c2) : 0.f;
+      sc[r] = pr * dp[r];
+    }
+  }
+  const bf16x8 ds0 = pack8(sc, 0), ds1 = pack8(sc, 1);
+#pragma unroll
+  for (int blk = 0; blk < G::NB; ++blk) {
+    dq[blk] = mma32(lds_tr_pair(Kt + fo.tr[0][blk], Kt + fo.tr[1][blk]), ds0, dq[blk]);
+    dq[blk] = mma32(lds_tr_pair(Kt + 16 * G::PITCH + fo.tr[0][blk], Kt + 16 * G::PITCH + fo.tr[1][blk]), ds1, dq[blk]);
+  }
+}
+
+// One 32-query tile for a wave that owns 32 keys (lane <-> key).  Qt / Gt: the tile's rows of Q / dO in swizzled images;
+// nl / nd: -lse / scale and -delta of the tile's 32 queries (LDS); kf / vf: the wave's K / V operand fragments;
+// dk / dv: dK^T / dV^T accumulators (register <-> channel as in q_step32).
+template <int D>
+__device__ __forceinline__ void k_step32(const char* Qt, const char* Gt, const float* nl, const float* nd,
+                                         const bf16x8 (&kf)[A32<D>::KS], const bf16x8 (&vf)[A32<D>::KS], const bool key_live,
+                                         const float c2, const int hi, const Frag32Off<D>& fo,
+                                         f32x16 (&dk)[A32<D>::NB], f32x16 (&dv)[A32<D>::NB]) {
+  using G = A32<D>;
+  f32x16 sc, dp;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {              // register 4 g + e <-> query 8 g + 4 hi + e
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>(nl + 8 * g + 4 * hi);
+    const f32x4 d4 = *reinterpret_cast<const f32x4*>(nd + 8 * g + 4 * hi);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sc[4 * g + e] = l4[e]; dp[4 * g + e] = d4[e]; }
+  }
+#pragma unroll
+  for (int s = 0; s < G::KS; ++s) {
+    sc = mma32(lds_b128(Qt + fo.b[s]), kf[s], sc);
+    dp = mma32(lds_b128(Gt + fo.b[s]), vf[s], dp);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float pr = key_live ? __builtin_amdgcn_exp2f(sc[r] * c2) : 0.f;
+    sc[r] = pr;
+    dp[r] = pr * dp[r];
+  }
+  const bf16x8 p0 = pack8(sc, 0), p1 = pack8(sc, 1), s0 = pack8(dp, 0), s1 = pack8(dp, 1);
+#pragma unroll
+  for (int blk = 0; blk < G::NB; ++blk) {
+    dv[blk] = mma32(lds_tr_pair(Gt + fo.tr[0][blk], Gt + fo.tr[1][blk]), p0, dv[blk]);
+    dk[blk] = mma32(lds_tr_pair(Qt + fo.tr[0][blk], Qt + fo.tr[1][blk]), s0, dk[blk]);
+    dv[blk] = mma32(lds_tr_pair(Gt + 16 * G::PITCH + fo.tr[0][blk], Gt + 16 * G::PITCH + fo.tr[1][blk]), p1, dv[blk]);
+    dk[blk] = mma32(lds_tr_pair(Qt + 16 * G::PITCH + fo.tr[0][blk], Qt + 16 * G::PITCH + fo.tr[1][blk]), s1, dk[blk]);
+  }
+}
+
+// a wave's [d][32] accumulator block (lane <-> row of the tensor, register <-> channel) -> bf16 rows in global memory
+template <int D>
+__device__ __forceinline__ void store_rows32(bf16* row_ptr, const f32x16 (&acc)[A32<D>::NB], const float mul, const int hi) {
+#pragma unroll
+  for (int blk = 0; blk < A32<D>::NB; ++blk)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const bf16x4 o = {(bf16)(acc[blk][4 * g + 0] * mul), (bf16)(acc[blk][4 * g + 1] * mul),
+                        (bf16)(acc[blk][4 * g + 2] * mul), (bf16)(acc[blk][4 * g + 3] * mul)};
+      *reinterpret_cast<bf16x4*>(row_ptr + 32 * blk + 8 * g + 4 * hi) = o;
+    }
+}
+
+// the text keys' partial dK_c^T / dV_c^T blocks of a wave -> the block's fp32 reduction buffer red[2][D][32] (LDS)
+template <int D>
+__device__ __forceinline__ void reduce_text32(float* red, const f32x16 (&dk)[A32<D>::NB], const f32x16 (&dv)[A32<D>::NB],
+                                              const int n, const int hi) {
+#pragma unroll
+  for (int blk = 0; blk < A32<D>::NB; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      atomicAdd(red + ch * 32 + n, dk[blk][r]);
+      atomicAdd(red + (D + ch) * 32 + n, dv[blk][r]);
+    }
+}
+// ... and from there to dK_c / dV_c rows (whole block; `nthreads` threads)
+template <int D>
+__device__ __forceinline__ void store_text32(const float* red, const AttnArgs& p, const int b, const int h, const int S,
+                                             const int tid, const int nthreads) {
+  constexpr int CPR = A32<D>::CPR;
+  for (int i = tid; i < 2 * 32 * CPR; i += nthreads) {
+    const int t = i / (32 * CPR), rem_ = i - t * (32 * CPR);
+    const int cc = rem_ / 32, key = rem_ - cc * 32;        // consecutive threads <-> consecutive keys: conflict-free LDS reads
+    if (key >= S) continue;
+    const float mul = t ? 1.f : p.scale;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)(red[(t * D + cc * 8 + e) * 32 + key] * mul);
+    bf16* dst = reinterpret_cast<bf16*>(t ? p.dvc : p.dkc) + (size_t)b * p.dkc_bs + (size_t)h * D + (size_t)key * p.dkc_rs + cc * 8;
+    *reinterpret_cast<bf16x8*>(dst) = o;
+  }
+}
+
+// live text keys of batch element b as a bit mask (bit k: k < S and mask[b][k] != 0); wave-uniform, S <= 32
+__device__ __forceinline__ unsigned text_mask32(const AttnArgs& p, const int b, const int S, const int lane) {
+  bool live = lane < S;
+  if (live && p.mask) live = p.mask[(size_t)b * p.S + lane] != 0.f;
+  return (unsigned)__ballot(live);
+}
+
+// delta_self = rowsum(dO o (O - O_c)), delta_cross = rowsum(dO o O_c) of query row qi from the dO operand fragments a lane
+// already holds (elements 16 s + 8 hi .. + 7 of the row; the two halves of a row sit in lanes n and n + 32)
+template <int D>
+__device__ __forceinline__ void delta32(const bf16x8 (&gf)[A32<D>::KS], const RowSrc& osrc, const bf16* Ocp, const int o_rs,
+                                        const int qi, const bool qok, const int hi, float& a, float& c) {
+  a = 0.f; c = 0.f;
+#pragma unroll
+  for (int s = 0; s < A32<D>::KS; ++s) {
+    const bf16x8 of = osrc.frag(qi, s, hi);
+    bf16x8 cf = bf16x8{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    if (Ocp && qok) cf = *reinterpret_cast<const bf16x8*>(Ocp + (size_t)qi * o_rs + 16 * s + 8 * hi);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gv = (float)gf[s][e], ov = (float)of[e], cv = (float)cf[e];
+      a += gv * (ov - cv);
+      c += gv * cv;
+    }
+  }
+  a += __shfl_xor(a, 32, 64);
+  c += __shfl_xor(c, 32, 64);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Short sequences (L <= 256 queries, S <= 32 text keys, d = 64 / 96, bf16): the whole backward of one (batch, head) in
+// one block of 8 waves, every operand LDS-resident once.
+//   stage    K, V, K_c, V_c, Q -> LDS images (all global loads of the stage in flight before the first LDS store)
+//   phase Q  a wave owns 32 queries (Q, dO operand fragments and delta = rowsum(dO o O) in registers): for every 32-key
+//            tile S^T' = K Q^T - lse / scale, dP^T' = V dO^T - delta (lane <-> query: lse and delta are per-lane scalars),
+//            dS^T = 2^(c2 S^T') dP^T', dQ^T += K^T dS^T.  lse' and delta rows of the head go to LDS for phase K.
+//   switch   dO -> the LDS region K leaves (Q is already resident)
+//   phase K  a wave owns 32 keys (K, V operand fragments in registers): for every 32-query tile S' = Q K^T + lse' (C operand),
+//            dP' = dO V^T + (-delta), P = 2^(c2 S'), dS = P dP', dV^T += dO^T P, dK^T += Q^T dS.
+//            The text keys are one more 32-key tile: wave w takes it against ITS query tile w, the eight partial
+//            [d][32] blocks are summed in LDS (ds_add_f32) and written by the whole block.
+// 7 matmuls (S and dP in both phases): keeping dS for the other phase would take 128 KB next to 144 KB of operands.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
+  using T = bf16;
+  using G = A32<D>;
+  constexpr int KS = G::KS, NB = G::NB, CPR = G::CPR, PITCH = G::PITCH;
+  constexpr int TILE = 256 * PITCH;          // a 256-row image
+  constexpr int CT = 32 * PITCH;             // a text image (32 rows)
+  constexpr int T32 = 32 * PITCH;            // one 32-row tile inside an image
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const R0 = smem;                     // K, then dO
+  char* const R1 = smem + TILE;              // V, then the text keys' reduction buffer
+  char* const R2 = smem + 2 * TILE;          // Q
+  char* const KC = smem + 3 * TILE;
+  char* const VC = KC + CT;
+  float* const fl = reinterpret_cast<float*>(VC + CT);
+  float* const nlse_self = fl;               // [256] each: -lse / scale (queries past L: -1e30), -delta
+  float* const nlse_cross = fl + 256;
+  float* const ndel_self = fl + 512;
+  float* const ndel_cross = fl + 768;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, hi = lane >> 5;
+  const Frag32Off<D> fo(lane);
+  const int bh = xcd_remap((int)blockIdx.x, (int)gridDim.x);   // consecutive (batch, head) on one XCD: their rows share lines
+  const int b = bh / p.H, h = bh - b * p.H;
+  const bool has_c = p.kc != nullptr;
+  const int L = p.L, S = has_c ? p.S : 0;
+  const int nt = (L + 31) >> 5;              // 32-row tiles (queries = self keys), <= 8
+  const float c2 = p.scale * LOG2E;
+  const float inv_scale = 1.0f / p.scale;
+
+  const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * D;
+  const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)b * p.k_bs + (size_t)h * D;
+  const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)b * p.k_bs + (size_t)h * D;
+  const T* DOp = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.o_bs + (size_t)h * D;
+  const T* Op = reinterpret_cast<const T*>(p.out) + (size_t)b * p.o_bs + (size_t)h * D;
+  const T* Kcp = has_c ? reinterpret_cast<const T*>(p.kc) + (size_t)b * p.c_bs + (size_t)h * D : Kp;
+  const T* Vcp = has_c ? reinterpret_cast<const T*>(p.vc) + (size_t)b * p.c_bs + (size_t)h * D : Vp;
+  const T* Ocp = (has_c && p.out_cross) ? reinterpret_cast<const T*>(p.out_cross) + (size_t)b * p.o_bs + (size_t)h * D : nullptr;
+  const RowSrc qsrc(Qp, p.q_rs, L), ksrc(Kp, p.k_rs, L), vsrc(Vp, p.k_rs, L), gsrc(DOp, p.o_rs, L), osrc(Op, p.o_rs, L);
+  const RowSrc kcsrc(Kcp, has_c ? p.c_rs : p.k_rs, S), vcsrc(Vcp, has_c ? p.c_rs : p.k_rs, S);
+
+  const unsigned tmask = has_c ? text_mask32(p, b, S, lane) : 0u;   // live text keys (wave-uniform bit mask)
+
+  // `rows` rows of a head view -> a swizzled image; chunk c of the call = row c / CPR, chunk c % CPR
+  constexpr int NV = (256 * CPR + 511) / 512;
+  auto stage_fetch = [&](uint4 (&v)[NV], const RowSrc& src, int rows) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = tid + i * 512;
+      const int row = c / CPR, cc = c - row * CPR;
+      v[i] = uint4{0u, 0u, 0u, 0u};
+      if (c < rows * CPR) v[i] = src.chunk(row, cc * 16);
+    }
+  };
+  auto stage_commit = [&](char* dst, const uint4 (&v)[NV], int rows) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = tid + i * 512;
+      const int row = c / CPR, cc = c - row * CPR;
+      if (c < rows * CPR) *reinterpret_cast<uint4*>(dst + G::off(row, cc)) = v[i];
+    }
+  };
+
+  // ---- stage ------------------------------------------------------------------------------------------------------
+  {
+    uint4 kv[NV], vv[NV], qv[NV];
+    stage_fetch(kv, ksrc, nt * 32);
+    stage_fetch(vv, vsrc, nt * 32);
+    stage_fetch(qv, qsrc, nt * 32);
+    uint4 tc = uint4{0u, 0u, 0u, 0u};
+    const int trow = (tid & 255) / CPR, tcc = (tid & 255) - trow * CPR;    // 32 x CPR <= 384 chunks per text image
+    uint4 tc2 = uint4{0u, 0u, 0u, 0u};
+    if (has_c) {
+      // threads 0-255: chunks 0-255 of K_c, threads 256-511: of V_c; the remaining 32 CPR - 256 chunks in a second round
+      const RowSrc& ts = tid < 256 ? kcsrc : vcsrc;
+      tc = ts.chunk(trow, tcc * 16);
+      if (32 * CPR > 256) {
+        const int c = 256 + (tid & 255);
+        const int r2 = c / CPR, c2_ = c - r2 * CPR;
+        if (c < 32 * CPR) tc2 = ts.chunk(r2, c2_ * 16);
+      }
+    }
+    stage_commit(R0, kv, nt * 32);
+    stage_commit(R1, vv, nt * 32);
+    stage_commit(R2, qv, nt * 32);
+    if (has_c) {
+      char* timg = tid < 256 ? KC : VC;
+      *reinterpret_cast<uint4*>(timg + G::off(trow, tcc)) = tc;
+      if (32 * CPR > 256) {
+        const int c = 256 + (tid & 255);
+        const int r2 = c / CPR, c2_ = c - r2 * CPR;
+        if (c < 32 * CPR) *reinterpret_cast<uint4*>(timg + G::off(r2, c2_)) = tc2;
+      }
+    }
+  }
+
+  // ---- phase Q ----------------------------------------------------------------------------------------------------
+  const int q0 = wave * 32;
+  const bool q_active = __builtin_amdgcn_readfirstlane(q0) < L;
+  if (q_active) {
+    const int qi = q0 + n;
+    bf16x8 qf[KS], gf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      qf[s] = qsrc.frag(qi, s, hi);
+      gf[s] = gsrc.frag(qi, s, hi);
+    }
+    float a, c;
+    delta32<D>(gf, osrc, Ocp, p.o_rs, qi, qi < L, hi, a, c);
+    const size_t lo = ((size_t)b * p.H + h) * L + (qi < L ? qi : 0);
+    const bool qok = qi < L;
+    const float nls = qok ? -p.lse_self[lo] * inv_scale : -1e30f;
+    const float nlc = (qok && has_c) ? -p.lse_cross[lo] * inv_scale : -1e30f;
+    const float nds = qok ? -a : 0.f, ndc = qok ? -c : 0.f;
+    if (hi == 0) {
+      nlse_self[qi] = nls; nlse_cross[qi] = nlc; ndel_self[qi] = nds; ndel_cross[qi] = ndc;
+    }
+    __syncthreads();                         // (all 512 threads reach one of the two barriers of this if / else)
+
+    f32x16 dq[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) dq[blk] = splat16(0.f);
+    const int ntile = nt + (has_c ? 1 : 0);
+    for (int kt = 0; kt < ntile; ++kt) {
+      const bool cross = kt >= nt;
+      const char* Kt = cross ? KC : R0 + kt * T32;
+      const char* Vt = cross ? VC : R1 + kt * T32;
+      const int rem = L - kt * 32;
+      const unsigned live = cross ? tmask : (rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u));
+      q_step32<D>(Kt, Vt, qf, gf, cross ? nlc : nls, cross ? ndc : nds, live, c2, hi, fo, dq);
+    }
+    // dQ^T: lane <-> query, register r <-> channel 32 blk + 8 (r >> 2) + 4 hi + (r & 3)
+    if (qok) store_rows32<D>(reinterpret_cast<T*>(p.dq) + (size_t)b * p.q_bs + (size_t)h * D + (size_t)qi * p.q_rs, dq, p.scale, hi);
+  } else {
+    __syncthreads();
+  }
+
+  // ---- switch: dO -> R0, the reduction buffer of the text keys (R1) cleared ------------------------------------------
+  __syncthreads();                           // every wave is done with K, V, K_c, V_c
+  {
+    uint4 gv[NV];
+    stage_fetch(gv, gsrc, nt * 32);
+    if (has_c) {
+      float* red = reinterpret_cast<float*>(R1);
+      for (int i = tid; i < 2 * D * 32; i += 512) red[i] = 0.f;
+    }
+    stage_commit(R0, gv, nt * 32);
+  }
+  __syncthreads();
+
+  // ---- phase K ----------------------------------------------------------------------------------------------------
+  const int k0 = wave * 32;
+  if (__builtin_amdgcn_readfirstlane(k0) < L) {
+    const int key = k0 + n;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kf[s] = ksrc.frag(key, s, hi);
+      vf[s] = vsrc.frag(key, s, hi);
+    }
+    f32x16 dk[NB], dv[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) { dk[blk] = splat16(0.f); dv[blk] = splat16(0.f); }
+    for (int qt = 0; qt < nt; ++qt)
+      k_step32<D>(R2 + qt * T32, R0 + qt * T32, nlse_self + qt * 32, ndel_self + qt * 32, kf, vf, key < L, c2, hi, fo, dk, dv);
+    if (key < L) {
+      const size_t ro = (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key * p.dk_rs;
+      store_rows32<D>(reinterpret_cast<T*>(p.dk) + ro, dk, p.scale, hi);
+      store_rows32<D>(reinterpret_cast<T*>(p.dv) + ro, dv, 1.f, hi);
+    }
+  }
+  if (has_c) {
+    float* red = reinterpret_cast<float*>(R1);   // [2][D][32 keys]: dK_c^T, dV_c^T
+    if (q_active) {                              // this wave's query tile (index `wave`) against the text keys
+      bf16x8 kf[KS], vf[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        kf[s] = kcsrc.frag(n, s, hi);
+        vf[s] = vcsrc.frag(n, s, hi);
+      }
+      f32x16 dk[NB], dv[NB];
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) { dk[blk] = splat16(0.f); dv[blk] = splat16(0.f); }
+      k_step32<D>(R2 + wave * T32, R0 + wave * T32, nlse_cross + wave * 32, ndel_cross + wave * 32, kf, vf,
+                  ((tmask >> n) & 1u) != 0u, c2, hi, fo, dk, dv);
+      reduce_text32<D>(red, dk, dv, n, hi);
+    }
+    __syncthreads();
+    store_text32<D>(red, p, b, h, S, tid, 512);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Long sequences (L > 256: the 32x32 level of the U-Net, L = 1024, d = 64): two streaming kernels on the same tile steps.
+//
+// attn_bwd_dq32_kernel   block = 256 queries of one (batch, head), 8 waves x 32 queries (Q, dO operand fragments, lse, delta in
+//   registers; delta = rowsum(dO o O) is computed here and stored for the dK / dV kernel).  The keys stream through LDS in
+//   stages of 64 (K and V rows, double-buffered: the next stage's global loads are in flight during this stage's MFMAs and
+//   are committed after them; one barrier per stage); the text keys are one more stage.
+// attn_bwd_dkv32_kernel  block = 256 keys, 8 waves x 32 keys (K, V operand fragments in registers); the queries stream
+//   through LDS in stages of 64 (Q and dO rows + their -lse / scale and -delta).  The text keys of a (batch, head) are ONE
+//   more block whose waves each take every 8th 32-query tile (staged privately per wave: no block barrier in that loop)
+//   and sum their partial dK_c^T / dV_c^T in LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D> struct Stream32 {
+  using G = A32<D>;
+  static constexpr int HALF = 64 * G::PITCH;                 // one tensor's 64 rows
+  static constexpr int NVS = 2 * 64 * G::CPR / 512;          // 16-byte chunks per thread and stage (two tensors)
+  static_assert(2 * 64 * G::CPR % 512 == 0, "stage chunks divide over 512 threads");
+  // chunk i of thread tid: tensor (c / (64 CPR)), row, chunk
+  static __device__ __forceinline__ void fetch(uint4 (&v)[NVS], const RowSrc& a, const RowSrc& b_, int row0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NVS; ++i) {
+      const int c = tid + i * 512;
+      const int which = c / (64 * G::CPR), c1 = c - which * (64 * G::CPR);
+      const int row = c1 / G::CPR, cc = c1 - row * G::CPR;
+      v[i] = (which ? b_ : a).chunk(row0 + row, cc * 16);
+    }
+  }
+  static __device__ __forceinline__ void commit(char* stage, const uint4 (&v)[NVS], int tid) {
+#pragma unroll
+    for (int i = 0; i < NVS; ++i) {
+      const int c = tid + i * 512;
+      const int which = c / (64 * G::CPR), c1 = c - which * (64 * G::CPR);
+      const int row = c1 / G::CPR, cc = c1 - row * G::CPR;
+      *reinterpret_cast<uint4*>(stage + which * HALF + G::off(row, cc)) = v[i];
+    }
+  }
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 1) void attn_bwd_dq32_kernel(AttnArgs p) {
+  using T = bf16;
+  using G = A32<D>;
+  using ST = Stream32<D>;
+  constexpr int KS = G::KS, NB = G::NB, PITCH = G::PITCH, T32 = 32 * PITCH;
+  constexpr int STAGE = 2 * ST::HALF;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, hi = lane >> 5;
+  const Frag32Off<D> fo(lane);
+  const int bx_ = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int by = bx_ / (int)gridDim.x, bx = bx_ - by * (int)gridDim.x;
+  const int b = by / p.H, h = by - b * p.H;
+  const bool has_c = p.kc != nullptr;
+  const int L = p.L, S = has_c ? p.S : 0;
+  const float c2 = p.scale * LOG2E, inv_scale = 1.0f / p.scale;
+
+  const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * D;
+  const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)b * p.k_bs + (size_t)h * D;
+  const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)b * p.k_bs + (size_t)h * D;
+  const T* DOp = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.o_bs + (size_t)h * D;
+  const T* Op = reinterpret_cast<const T*>(p.out) + (size_t)b * p.o_bs + (size_t)h * D;
+  const T* Kcp = has_c ? reinterpret_cast<const T*>(p.kc) + (size_t)b * p.c_bs + (size_t)h * D : Kp;
+  const T* Vcp = has_c ? reinterpret_cast<const T*>(p.vc) + (size_t)b * p.c_bs + (size_t)h * D : Vp;
+  const T* Ocp = (has_c && p.out_cross) ? reinterpret_cast<const T*>(p.out_cross) + (size_t)b * p.o_bs + (size_t)h * D : nullptr;
+  const RowSrc qsrc(Qp, p.q_rs, L), ksrc(Kp, p.k_rs, L), vsrc(Vp, p.k_rs, L), gsrc(DOp, p.o_rs, L), osrc(Op, p.o_rs, L);
+  const RowSrc kcsrc(Kcp, has_c ? p.c_rs : p.k_rs, S), vcsrc(Vcp, has_c ? p.c_rs : p.k_rs, S);
+  const unsigned tmask = has_c ? text_mask32(p, b, S, lane) : 0u;
+
+  const int q0 = bx * 256 + wave * 32, qi = q0 + n;
+  const bool w_active = __builtin_amdgcn_readfirstlane(q0) < L, qok = qi < L;
+  bf16x8 qf[KS], gf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    qf[s] = qsrc.frag(qi, s, hi);
+    gf[s] = gsrc.frag(qi, s, hi);
+  }
+  const int nself = (L + 63) >> 6, ntot = nself + (has_c ? 1 : 0);
+  uint4 stg[ST::NVS];
+  ST::fetch(stg, ksrc, vsrc, 0, tid);
+  float a, c;
+  delta32<D>(gf, osrc, Ocp, p.o_rs, qi, qok, hi, a, c);
+  const size_t lo = ((size_t)b * p.H + h) * L + (qok ? qi : 0);
+  if (qok && hi == 0) {
+    p.delta_self_w[lo] = a;
+    if (p.delta_cross_w) p.delta_cross_w[lo] = c;
+  }
+  const float nls = qok ? -p.lse_self[lo] * inv_scale : -1e30f;
+  const float nlc = (qok && has_c) ? -p.lse_cross[lo] * inv_scale : -1e30f;
+  const float nds = qok ? -a : 0.f, ndc = qok ? -c : 0.f;
+  ST::commit(smem, stg, tid);
+
+  f32x16 dq[NB];
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) dq[blk] = splat16(0.f);
+  // stage t out of LDS buffer CUR (compile-time: every fragment address is per-lane offset + immediate)
+  auto stage = [&](auto cur_c, const int t) {
+    constexpr int CUR = decltype(cur_c)::value;
+    const char* Ks = smem + CUR * STAGE;
+    const char* Vs = Ks + ST::HALF;
+    __syncthreads();
+    const bool more = t + 1 < ntot;
+    if (more) {
+      if (t + 1 < nself) ST::fetch(stg, ksrc, vsrc, (t + 1) * 64, tid);
+      else ST::fetch(stg, kcsrc, vcsrc, 0, tid);
+    }
+    if (w_active) {
+      const bool cross = t >= nself;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int rem = cross ? 0 : L - (t * 64 + sub * 32);
+        const unsigned live = cross ? (sub == 0 ? tmask : 0u) : (rem >= 32 ? 0xffffffffu : (rem > 0 ? ((1u << rem) - 1u) : 0u));
+        if (live == 0u) continue;              // (wave-uniform) no key of this half takes part
+        q_step32<D>(Ks + sub * T32, Vs + sub * T32, qf, gf, cross ? nlc : nls, cross ? ndc : nds, live, c2, hi, fo, dq);
+      }
+    }
+    if (more) ST::commit(smem + (1 - CUR) * STAGE, stg, tid);
+  };
+  for (int t = 0; t < ntot; t += 2) {
+    stage(IntC<0>{}, t);
+    if (t + 1 < ntot) stage(IntC<1>{}, t + 1);
+  }
+  if (qok) store_rows32<D>(reinterpret_cast<T*>(p.dq) + (size_t)b * p.q_bs + (size_t)h * D + (size_t)qi * p.q_rs, dq, p.scale, hi);
+}
+
+template <int D>
+__global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
+  using T = bf16;
+  using G = A32<D>;
+  using ST = Stream32<D>;
+  constexpr int KS = G::KS, NB = G::NB, CPR = G::CPR, PITCH = G::PITCH, T32 = 32 * PITCH;
+  constexpr int STAGE = 2 * ST::HALF + 512;                    // Q rows | dO rows | -lse / scale [64] | -delta [64]
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, hi = lane >> 5;
+  const Frag32Off<D> fo(lane);
+  const int bx_ = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int by = bx_ / (int)gridDim.x, bx = bx_ - by * (int)gridDim.x;
+  const int b = by / p.H, h = by - b * p.H;
+  const bool has_c = p.kc != nullptr;
+  const int L = p.L, S = has_c ? p.S : 0;
+  const float c2 = p.scale * LOG2E, inv_scale = 1.0f / p.scale;
+  const int nself_blocks = (L + 255) >> 8;
+
+  const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * D;
+  const T* DOp = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.o_bs + (size_t)h * D;
+  const RowSrc qsrc(Qp, p.q_rs, L), gsrc(DOp, p.o_rs, L);
+  const size_t lrow = ((size_t)b * p.H + h) * L;
+
+  if (bx < nself_blocks) {
+    // ---- 256 self keys ------------------------------------------------------------------------------------------------
+    const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)b * p.k_bs + (size_t)h * D;
+    const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)b * p.k_bs + (size_t)h * D;
+    const RowSrc ksrc(Kp, p.k_rs, L), vsrc(Vp, p.k_rs, L);
+    const int k0 = bx * 256 + wave * 32, key = k0 + n;
+    const bool w_active = __builtin_amdgcn_readfirstlane(k0) < L;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kf[s] = ksrc.frag(key, s, hi);
+      vf[s] = vsrc.frag(key, s, hi);
+    }
+    const int nst = (L + 63) >> 6;
+    uint4 stg[ST::NVS];
+    float fl_r = 0.f;                          // threads 0-63: -lse / scale, 64-127: -delta of query row0 + (tid & 63)
+    auto fetch_fl = [&](int row0) {
+      if (tid < 128) {
+        const int q = row0 + (tid & 63);
+        const bool ok = q < L;
+        if (tid < 64) fl_r = ok ? -p.lse_self[lrow + q] * inv_scale : -1e30f;
+        else fl_r = ok ? -p.delta_self[lrow + q] : 0.f;
+      }
+    };
+    ST::fetch(stg, qsrc, gsrc, 0, tid);
+    fetch_fl(0);
+    ST::commit(smem, stg, tid);
+    if (tid < 128) reinterpret_cast<float*>(smem + 2 * ST::HALF)[tid] = fl_r;
+
+    f32x16 dk[NB], dv[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) { dk[blk] = splat16(0.f); dv[blk] = splat16(0.f); }
+    auto stage = [&](auto cur_c, const int t) {
+      constexpr int CUR = decltype(cur_c)::value;
+      const char* Qs = smem + CUR * STAGE;
+      const char* Gs = Qs + ST::HALF;
+      const float* nl = reinterpret_cast<const float*>(Qs + 2 * ST::HALF);
+      __syncthreads();
+      const bool more = t + 1 < nst;
+      if (more) {
+        ST::fetch(stg, qsrc, gsrc, (t + 1) * 64, tid);
+        fetch_fl((t + 1) * 64);
+      }
+      if (w_active) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          if (t * 64 + sub * 32 >= L) continue;   // (uniform) no query in this half
+          k_step32<D>(Qs + sub * T32, Gs + sub * T32, nl + sub * 32, nl + 64 + sub * 32, kf, vf, key < L, c2, hi, fo, dk, dv);
+        }
+      }
+      if (more) {
+        char* nb = smem + (1 - CUR) * STAGE;
+        ST::commit(nb, stg, tid);
+        if (tid < 128) reinterpret_cast<float*>(nb + 2 * ST::HALF)[tid] = fl_r;
+      }
+    };
+    for (int t = 0; t < nst; t += 2) {
+      stage(IntC<0>{}, t);
+      if (t + 1 < nst) stage(IntC<1>{}, t + 1);
+    }
+    if (key < L) {
+      const size_t ro = (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key * p.dk_rs;
+      store_rows32<D>(reinterpret_cast<T*>(p.dk) + ro, dk, p.scale, hi);
+      store_rows32<D>(reinterpret_cast<T*>(p.dv) + ro, dv, 1.f, hi);
+    }
+    return;
+  }
+
+  // ---- the text keys: wave w takes query tiles w, w + 8, ... (private LDS tile per wave) ------------------------------------
+  const T* Kcp = reinterpret_cast<const T*>(p.kc) + (size_t)b * p.c_bs + (size_t)h * D;
+  const T* Vcp = reinterpret_cast<const T*>(p.vc) + (size_t)b * p.c_bs + (size_t)h * D;
+  const RowSrc kcsrc(Kcp, p.c_rs, S), vcsrc(Vcp, p.c_rs, S);
+  const unsigned tmask = text_mask32(p, b, S, lane);
+  constexpr int PRIV = 2 * T32 + 256;                          // Q tile | dO tile | -lse / scale [32] | -delta [32]
+  char* const mine = smem + wave * PRIV;
+  float* const red = reinterpret_cast<float*>(smem + 8 * PRIV);   // [2][D][32]
+  for (int i = tid; i < 2 * D * 32; i += 512) red[i] = 0.f;
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    kf[s] = kcsrc.frag(n, s, hi);
+    vf[s] = vcsrc.frag(n, s, hi);
+  }
+  f32x16 dk[NB], dv[NB];
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) { dk[blk] = splat16(0.f); dv[blk] = splat16(0.f); }
+  const int nt = (L + 31) >> 5;
+  constexpr int NVP = 32 * CPR / 64;                           // chunks per lane and tensor of a 32-row tile
+  for (int qt = wave; qt < nt; qt += 8) {
+    uint4 qv[NVP], gv[NVP];
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+      const int c = lane + i * 64;
+      const int row = c / CPR, cc = c - row * CPR;
+      qv[i] = qsrc.chunk(qt * 32 + row, cc * 16);
+      gv[i] = gsrc.chunk(qt * 32 + row, cc * 16);
+    }
+    const int q = qt * 32 + n;
+    float f = 0.f;
+    if (hi == 0) f = q < L ? -p.lse_cross[lrow + q] * inv_scale : -1e30f;
+    else f = q < L ? -p.delta_cross[lrow + q] : 0.f;
+    __builtin_amdgcn_wave_barrier();                           // (the previous tile's LDS reads are issued before these writes)
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+      const int c = lane + i * 64;
+      const int row = c / CPR, cc = c - row * CPR;
+      *reinterpret_cast<uint4*>(mine + G::off(row, cc)) = qv[i];
+      *reinterpret_cast<uint4*>(mine + T32 + G::off(row, cc)) = gv[i];
+    }
+    reinterpret_cast<float*>(mine + 2 * T32)[lane] = f;        // lanes 0-31: -lse / scale, 32-63: -delta
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float* nl = reinterpret_cast<const float*>(mine + 2 * T32);
+    k_step32<D>(mine, mine + T32, nl, nl + 32, kf, vf, ((tmask >> n) & 1u) != 0u, c2, hi, fo, dk, dv);
+  }
+  __syncthreads();                                             // red is cleared
+  reduce_text32<D>(red, dk, dv, n, hi);
+  __syncthreads();
+  store_text32<D>(red, p, b, h, S, tid, 512);
+}
+
+template <int D> constexpr int attn_bwd_dq32_lds() { return 2 * 2 * 64 * 2 * D; }
+template <int D> constexpr int attn_bwd_dkv32_lds() {
+  return (2 * (2 * 64 * 2 * D + 512)) > (8 * (2 * 32 * 2 * D + 256) + 2 * D * 32 * 4) ? (2 * (2 * 64 * 2 * D + 512))
+                                                                                      : (8 * (2 * 32 * 2 * D + 256) + 2 * D * 32 * 4);
+}
+
+template <int D> constexpr int attn_bwd_small32_lds() { return 3 * 256 * 2 * D + 2 * 32 * 2 * D + 4096; }
+
+}  // namespace mdm

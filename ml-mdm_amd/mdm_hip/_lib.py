@@ -32,7 +32,7 @@ class MdmHipError(RuntimeError):
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source for gfx950 into ml-mdm_amd/mdm_hip/libmdm_hip.so (in-tree)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, h) for h in ("common.hpp", "conv_args.hpp", "gemm_x.hpp")]
+    hdrs = [os.path.join(CSRC, h) for h in ("common.hpp", "conv_args.hpp", "gemm_x.hpp", "attn32.hpp")]
     deps = srcs + [HEADER] + hdrs
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
@@ -133,7 +133,7 @@ def _apply_dev_env(handle):
     include/mdm_hip_dev.h -- the C entry points themselves never look at the environment."""
     mode = os.environ.get("MDM_HIP_ATTN_BWD")
     if mode:
-        handle.mdm_dev_set_attn_bwd({"split": 1, "small": 2}.get(mode, 0))
+        handle.mdm_dev_set_attn_bwd({"split": 1, "small": 2, "small16": 3, "stream32": 4}.get(mode, 0))
     if os.environ.get("MDM_HIP_SPLIT_FILL"):
         handle.mdm_dev_set_knob(6, int(os.environ["MDM_HIP_SPLIT_FILL"]))
     if os.environ.get("MDM_HIP_CONV_DIRECT") == "0":

@@ -595,6 +595,12 @@ def _attn_ref(qkv, kvc, mask, heads):
     (2, 72, 64, 2, 128, False),       # d = 128, a full text tile, L barely over one tile
     (2, 136, 0, 2, 96, False),        # no cross attention, second 128-key / 128-query pass partial
     (40, 64, 8, 8, 32, True),         # B * H = 320 blocks: more heads than CUs (second round of blocks)
+    # csrc/attn32.hpp (d = 64 / 96, at most 32 text keys): a wave owns 32 keys / queries
+    (2, 256, 32, 8, 96, True),        # UNet-64 level 2 geometry, masked text
+    (40, 96, 20, 8, 64, True),        # 320 heads, three 32-row tiles, ragged text
+    (2, 1000, 20, 2, 64, True),       # streaming kernels: ragged L (last stage of 64 partial, last 256-row block partial)
+    (1, 320, 32, 2, 96, False),       # streaming kernels at d = 96, second block of 256 rows mostly empty
+    (2, 33, 3, 1, 64, True),          # one row into the second tile
 ])
 def test_attention(dtype, B, L, S, H, d, masked, request):
     from mdm_hip import _lib, ops
@@ -629,15 +635,18 @@ def test_attention(dtype, B, L, S, H, d, masked, request):
     assert relerr(qd.grad.float().cpu(), qkv.grad) < tol
     if S:
         assert relerr(kd.grad.float().cpu(), kvc.grad) < tol
-    if dtype == torch.bfloat16 and L <= 256 and S <= 64:
-        # ... and the two streaming kernels on the same case: both backward paths must agree with the reference
-        _lib.lib().mdm_dev_set_attn_bwd(1)
-        qd2 = qkv.detach().to(dtype).to(dev()).requires_grad_()
-        kd2 = kvc.detach().to(dtype).to(dev()).requires_grad_() if S else None
-        ops.attention(qd2, kd2, md, H).backward(go.to(dtype).to(dev()))
-        assert relerr(qd2.grad.float().cpu(), qkv.grad) < tol
-        if S:
-            assert relerr(kd2.grad.float().cpu(), kvc.grad) < tol
+    if dtype == torch.bfloat16:
+        # ... and every other backward path on the same case (mdm_hip_dev.h: 1 = the two streaming kernels on 16x16x32
+        # MFMAs, 3 = one block per head on 16x16x32, 4 = the streaming kernels on 32x32x16 of csrc/attn32.hpp where the
+        # shape allows): all must agree with the reference
+        for mode in (1, 3, 4):
+            _lib.lib().mdm_dev_set_attn_bwd(mode)
+            qd2 = qkv.detach().to(dtype).to(dev()).requires_grad_()
+            kd2 = kvc.detach().to(dtype).to(dev()).requires_grad_() if S else None
+            ops.attention(qd2, kd2, md, H).backward(go.to(dtype).to(dev()))
+            assert relerr(qd2.grad.float().cpu(), qkv.grad) < tol, mode
+            if S:
+                assert relerr(kd2.grad.float().cpu(), kvc.grad) < tol, mode
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
