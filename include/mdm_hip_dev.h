@@ -31,6 +31,9 @@ int mdm_dev_set_knob(int idx, int value);
  * one-block-per-head kernel whenever the shape allows (tests), 3 = as 2 but the 16x16x32 one, 4 = the streaming kernels on
  * 32x32x16 MFMAs (csrc/attn32.hpp) whenever the shape allows */
 int mdm_dev_set_attn_bwd(int mode);
+/* phase time stamps of attn_bwd_small32_kernel: a device buffer of [blocks][8][16] 64-bit words (tools/attn_debug.py), or
+ * null (the default) */
+int mdm_dev_set_attn_dbg(void* buf);
 
 #ifdef __cplusplus
 }

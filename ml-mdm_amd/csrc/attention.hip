@@ -44,6 +44,7 @@ struct AttnArgs {
   float* delta_self_w; float* delta_cross_w;                 // written by the dQ kernel, read by the dK/dV kernel
   int B, H, L, S;
   float scale;                                               // 1/sqrt(d)
+  unsigned long long* dbg;                                   // development aid (mdm_dev_set_attn_dbg): phase time stamps, or null
 };
 
 template <typename T> __device__ __forceinline__ void frag_from_global(Frag<T>& f, const T* p, bool valid);
@@ -1267,9 +1268,17 @@ extern "C" int mdm_dev_set_attn_bwd(int mode) {
   return 0;
 }
 
+// development aid: a device buffer of [blocks][8 waves][16] 64-bit shader-clock stamps written by attn_bwd_small32_kernel
+static unsigned long long* g_attn_dbg = nullptr;
+extern "C" int mdm_dev_set_attn_dbg(void* buf) {
+  g_attn_dbg = reinterpret_cast<unsigned long long*>(buf);
+  return 0;
+}
+
 template <typename T, int D>
 static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int dc_rs, hipStream_t st) {
   using G = AttnGeom<T, D>;
+  a.dbg = g_attn_dbg;
   constexpr int smem_q = sizeof(T) == 2 ? 4 * G::NAT_BYTES : 2 * G::NAT_BYTES + G::TR_BYTES;
   constexpr int smem_kv = sizeof(T) == 2 ? 2 * (2 * G::NAT_BYTES + 512) : 2 * G::NAT_BYTES + 2 * G::TR_BYTES + 512;
   // key tiles per wave of the dK / dV kernel: 2 where the registers allow it (the kernel is LDS-bandwidth bound: PMC
@@ -1299,7 +1308,10 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
         hipLaunchKernelGGL((attn_bwd_small32_kernel<D>), dim3(a.B * a.H), dim3(512), smem32, st, a);
         MDM_LAUNCH_STATUS();
       }
-      // long sequences (the 32x32 level: L = 1024): the same tile steps, keys / queries streamed through LDS
+    }
+    if constexpr (D == 64) {
+      // long sequences (the 32x32 level: L = 1024, d = 64): the same tile steps, keys / queries streamed through LDS
+      // (d = 96 would spill: 256 registers hold the accumulators and operands of a step, not the stream's staging on top)
       if (((a.L > 256 && g_attn_bwd_mode == 0) || g_attn_bwd_mode == 4) && (!a.kc || a.S <= 32)) {
         constexpr int smem_dq = attn_bwd_dq32_lds<D>(), smem_dkv = attn_bwd_dkv32_lds<D>();
         ensure_dynamic_lds(attn_bwd_dq32_kernel<D>, smem_dq);

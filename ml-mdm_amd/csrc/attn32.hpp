@@ -86,6 +86,15 @@ __device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, const 
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// "These fragments have arrived": an empty asm that reads them.  Placed in front of a loop whose body also has global loads in
+// flight, it keeps hipcc from waiting for THOSE inside the loop (its wait-count pass merges "the fragments loaded before the
+// loop may still be pending" into every iteration and then covers them with vmcnt(n) waits that, from the second iteration
+// on, can only be waiting for the loop's own prefetch).
+template <int N> __device__ __forceinline__ void frags_arrived(const bf16x8 (&f)[N]) {
+#pragma unroll
+  for (int s = 0; s < N; ++s) asm volatile("" ::"v"(f[s]));
+}
+
 // rows [0, nrows) of a strided head view behind a buffer descriptor: rows past the end read as zeros
 struct RowSrc {
   __amdgpu_buffer_rsrc_t rsrc;
@@ -105,49 +114,117 @@ struct RowSrc {
   }
 };
 
-// One 32-key tile for a wave that owns 32 queries (lane <-> query).  Kt / Vt: the tile's rows in a swizzled image; qf / gf:
-// the wave's Q / dO operand fragments; nl = -lse / scale, nd = -delta of the lane's query; `live`: bit k = key k of the
+// ---- the two tile steps -------------------------------------------------------------------------------------------------
+// Left to itself hipcc issues the LDS reads of a step two at a time, right in front of the MFMA pair that consumes them: a
+// wave then pays one LDS round trip per MFMA pair, then runs the softmax with nothing in flight, then pays the round trips
+// of the transpose reads -- measured 28 % of the matrix peak at L = 1024 with the arithmetic of a step at 12-24 MFMAs.  The
+// steps below are written as BATCHES separated by scheduling fences (sched_barrier): every read of a batch is issued
+// before the batch's consumers, and the batches are placed so that a read's latency lies under independent work:
+//     S / dP products (operands read one step earlier)  |  transpose reads of this tile issued  |  softmax (VALU)
+//     |  the NEXT tile's S / dP operands issued  |  dQ (dV, dK) products.
+// LDS returns in order, so the waits hipcc inserts are counted (lgkmcnt(n)), not drains.
+#define MDM_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef MDM_QPF96
+#define MDM_QPF96 3
+#endif
+#ifndef MDM_KPF96
+#define MDM_KPF96 3
+#endif
+
+// A operands (K, V rows: phase Q; Q, dO rows: phase K) of the S / dP products of one tile, read one step ahead
+template <int D, int PF> struct Ops32 { bf16x8 x[PF], y[PF]; };
+template <int D, int PF>
+__device__ __forceinline__ void load_ops32(Ops32<D, PF>& o, const char* Xt, const char* Yt, const Frag32Off<D>& fo) {
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    o.x[s] = lds_b128(Xt + fo.b[s]);
+    o.y[s] = lds_b128(Yt + fo.b[s]);
+  }
+}
+
+// One 32-key tile for a wave that owns 32 queries (lane <-> query).  Kt: the tile's K rows in a swizzled image; o: its K / V
+// operand fragments (read during the previous step); Kn / Vn: the NEXT tile's rows (any valid tile if there is none); qf /
+// gf: the wave's Q / dO operand fragments; nl = -lse / scale, nd = -delta of the lane's query; `live`: bit k = key k of the
 // tile takes part (wave-uniform); dq: dQ^T accumulators (register r of block blk <-> channel 32 blk + 8 (r >> 2) + 4 hi + (r & 3)).
+template <int D> struct QPf { static constexpr int value = D <= 64 ? A32<D>::KS : MDM_QPF96; };
 template <int D>
-__device__ __forceinline__ void q_step32(const char* Kt, const char* Vt, const bf16x8 (&qf)[A32<D>::KS], const bf16x8 (&gf)[A32<D>::KS],
+__device__ __forceinline__ void q_step32(Ops32<D, QPf<D>::value>& o, const char* Kt, const char* Vt, const char* Kn, const char* Vn,
+                                         const bf16x8 (&qf)[A32<D>::KS], const bf16x8 (&gf)[A32<D>::KS],
                                          const float nl, const float nd, const unsigned live, const float c2, const int hi,
                                          const Frag32Off<D>& fo, f32x16 (&dq)[A32<D>::NB]) {
   using G = A32<D>;
-  f32x16 sc = splat16(nl), dp = splat16(nd);
+  constexpr int PF = QPf<D>::value;
+  bf16x8 xr[G::KS - PF + 1], yr[G::KS - PF + 1];   // the reduction steps not read ahead (+ 1: no zero-length arrays)
 #pragma unroll
-  for (int s = 0; s < G::KS; ++s) {
-    sc = mma32(lds_b128(Kt + fo.b[s]), qf[s], sc);
-    dp = mma32(lds_b128(Vt + fo.b[s]), gf[s], dp);
+  for (int s = PF; s < G::KS; ++s) {
+    xr[s - PF] = lds_b128(Kt + fo.b[s]);
+    yr[s - PF] = lds_b128(Vt + fo.b[s]);
   }
+  // (lse and delta are per-lane scalars here: as initial accumulators they would cost 32 v_mov per tile, so the products start
+  // from the inline constant 0 and the scalars enter in the softmax: 2^(c2 S + c2 nl), P (dP + nd))
+  const f32x16 zero = splat16(0.f);
+  f32x16 sc, dp;
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    sc = mma32(o.x[s], qf[s], s == 0 ? zero : sc);
+    dp = mma32(o.y[s], gf[s], s == 0 ? zero : dp);
+  }
+#pragma unroll
+  for (int s = PF; s < G::KS; ++s) {
+    sc = mma32(xr[s - PF], qf[s], sc);
+    dp = mma32(yr[s - PF], gf[s], dp);
+  }
+  MDM_FENCE();
+  bf16x8 tk[2][G::NB];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int blk = 0; blk < G::NB; ++blk)
+      tk[s2][blk] = lds_tr_pair(Kt + s2 * 16 * G::PITCH + fo.tr[0][blk], Kt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
+  MDM_FENCE();
+  const float nl2 = nl * c2;
   if (live == 0xffffffffu) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r] * c2) * dp[r];
+    for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, nl2)) * (dp[r] + nd);
   } else {
     const unsigned lv = live >> (4 * hi);    // this lane's registers hold keys (r & 3) + 8 (r >> 2) + 4 hi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pr = ((lv >> ((r & 3) + 8 * (r >> 2))) & 1u) ? __builtin_amdgcn_exp2f(sc[r] * c2) : 0.f;
-      sc[r] = pr * dp[r];
+      const float pr = ((lv >> ((r & 3) + 8 * (r >> 2))) & 1u) ? __builtin_amdgcn_exp2f(fmaf(sc[r], c2, nl2)) : 0.f;
+      sc[r] = pr * (dp[r] + nd);
     }
   }
   const bf16x8 ds0 = pack8(sc, 0), ds1 = pack8(sc, 1);
+  MDM_FENCE();
+  load_ops32<D, PF>(o, Kn, Vn, fo);
+  MDM_FENCE();
 #pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) {
-    dq[blk] = mma32(lds_tr_pair(Kt + fo.tr[0][blk], Kt + fo.tr[1][blk]), ds0, dq[blk]);
-    dq[blk] = mma32(lds_tr_pair(Kt + 16 * G::PITCH + fo.tr[0][blk], Kt + 16 * G::PITCH + fo.tr[1][blk]), ds1, dq[blk]);
-  }
+  for (int blk = 0; blk < G::NB; ++blk) dq[blk] = mma32(tk[0][blk], ds0, dq[blk]);
+#pragma unroll
+  for (int blk = 0; blk < G::NB; ++blk) dq[blk] = mma32(tk[1][blk], ds1, dq[blk]);
 }
 
-// One 32-query tile for a wave that owns 32 keys (lane <-> key).  Qt / Gt: the tile's rows of Q / dO in swizzled images;
-// nl / nd: -lse / scale and -delta of the tile's 32 queries (LDS); kf / vf: the wave's K / V operand fragments;
-// dk / dv: dK^T / dV^T accumulators (register <-> channel as in q_step32).
+// One 32-query tile for a wave that owns 32 keys (lane <-> key).  Qt / Gt: the tile's rows of Q / dO in swizzled images; o:
+// the first PF reduction steps of their operand fragments (read during the previous step); Qn / Gn: the NEXT tile (any valid
+// tile if none); nl / nd: -lse / scale and -delta of the tile's 32 queries (LDS) -- they ARE the initial accumulators;
+// kf / vf: the wave's K / V operand fragments; dk / dv: dK^T / dV^T accumulators (register <-> channel as in q_step32).
+// PF: how many of the KS reduction steps are read one tile ahead (registers: all of them at d = 64, half at d = 96).
+template <int D> struct KPf { static constexpr int value = D <= 64 ? A32<D>::KS : MDM_KPF96; };
 template <int D>
-__device__ __forceinline__ void k_step32(const char* Qt, const char* Gt, const float* nl, const float* nd,
+__device__ __forceinline__ void k_step32(Ops32<D, KPf<D>::value>& o, const char* Qt, const char* Gt, const char* Qn, const char* Gn,
+                                         const float* nl, const float* nd,
                                          const bf16x8 (&kf)[A32<D>::KS], const bf16x8 (&vf)[A32<D>::KS], const bool key_live,
                                          const float c2, const int hi, const Frag32Off<D>& fo,
                                          f32x16 (&dk)[A32<D>::NB], f32x16 (&dv)[A32<D>::NB]) {
   using G = A32<D>;
+  constexpr int PF = KPf<D>::value;
   f32x16 sc, dp;
+  bf16x8 xr[G::KS - PF + 1], yr[G::KS - PF + 1];   // (+ 1: no zero-length arrays)
+#pragma unroll
+  for (int s = PF; s < G::KS; ++s) {
+    xr[s - PF] = lds_b128(Qt + fo.b[s]);
+    yr[s - PF] = lds_b128(Gt + fo.b[s]);
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {              // register 4 g + e <-> query 8 g + 4 hi + e
     const f32x4 l4 = *reinterpret_cast<const f32x4*>(nl + 8 * g + 4 * hi);
@@ -156,10 +233,23 @@ __device__ __forceinline__ void k_step32(const char* Qt, const char* Gt, const f
     for (int e = 0; e < 4; ++e) { sc[4 * g + e] = l4[e]; dp[4 * g + e] = d4[e]; }
   }
 #pragma unroll
-  for (int s = 0; s < G::KS; ++s) {
-    sc = mma32(lds_b128(Qt + fo.b[s]), kf[s], sc);
-    dp = mma32(lds_b128(Gt + fo.b[s]), vf[s], dp);
+  for (int s = 0; s < PF; ++s) {
+    sc = mma32(o.x[s], kf[s], sc);
+    dp = mma32(o.y[s], vf[s], dp);
   }
+#pragma unroll
+  for (int s = PF; s < G::KS; ++s) {
+    sc = mma32(xr[s - PF], kf[s], sc);
+    dp = mma32(yr[s - PF], vf[s], dp);
+  }
+  MDM_FENCE();
+  bf16x8 tg[2][G::NB];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int blk = 0; blk < G::NB; ++blk)
+      tg[s2][blk] = lds_tr_pair(Gt + s2 * 16 * G::PITCH + fo.tr[0][blk], Gt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
+  MDM_FENCE();
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float pr = key_live ? __builtin_amdgcn_exp2f(sc[r] * c2) : 0.f;
@@ -167,54 +257,92 @@ __device__ __forceinline__ void k_step32(const char* Qt, const char* Gt, const f
     dp[r] = pr * dp[r];
   }
   const bf16x8 p0 = pack8(sc, 0), p1 = pack8(sc, 1), s0 = pack8(dp, 0), s1 = pack8(dp, 1);
+  MDM_FENCE();
+  bf16x8 tq[2][G::NB];
 #pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) {
-    dv[blk] = mma32(lds_tr_pair(Gt + fo.tr[0][blk], Gt + fo.tr[1][blk]), p0, dv[blk]);
-    dk[blk] = mma32(lds_tr_pair(Qt + fo.tr[0][blk], Qt + fo.tr[1][blk]), s0, dk[blk]);
-    dv[blk] = mma32(lds_tr_pair(Gt + 16 * G::PITCH + fo.tr[0][blk], Gt + 16 * G::PITCH + fo.tr[1][blk]), p1, dv[blk]);
-    dk[blk] = mma32(lds_tr_pair(Qt + 16 * G::PITCH + fo.tr[0][blk], Qt + 16 * G::PITCH + fo.tr[1][blk]), s1, dk[blk]);
-  }
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int blk = 0; blk < G::NB; ++blk)
+      tq[s2][blk] = lds_tr_pair(Qt + s2 * 16 * G::PITCH + fo.tr[0][blk], Qt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
+  MDM_FENCE();
+#pragma unroll
+  for (int blk = 0; blk < G::NB; ++blk) dv[blk] = mma32(tg[0][blk], p0, dv[blk]);
+#pragma unroll
+  for (int blk = 0; blk < G::NB; ++blk) dv[blk] = mma32(tg[1][blk], p1, dv[blk]);
+  MDM_FENCE();
+  load_ops32<D, PF>(o, Qn, Gn, fo);
+  MDM_FENCE();
+#pragma unroll
+  for (int blk = 0; blk < G::NB; ++blk) dk[blk] = mma32(tq[0][blk], s0, dk[blk]);
+#pragma unroll
+  for (int blk = 0; blk < G::NB; ++blk) dk[blk] = mma32(tq[1][blk], s1, dk[blk]);
 }
 
-// a wave's [d][32] accumulator block (lane <-> row of the tensor, register <-> channel) -> bf16 rows in global memory
+// a wave's [d][32] accumulator block (lane <-> row of the tensor, register <-> channel) -> bf16 rows in global memory.
+// Lane (n, hi) holds channels 8 g + 4 hi + 0..3 of row n (g = r >> 2): 8-byte pieces.  One v_permlane32_swap per packed
+// register pairs the pieces of the two half-waves (hi = 0 takes channels 16 j .. 16 j + 7 of its row, hi = 1 channels
+// 16 j + 8 .. + 15), so a row leaves as 16-byte stores -- half the store instructions (the store tail of these kernels is
+// issue-bound, not bandwidth-bound).
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi_) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  bf16x2_t v = {(bf16)lo, (bf16)hi_};
+  return *reinterpret_cast<unsigned*>(&v);
+}
 template <int D>
-__device__ __forceinline__ void store_rows32(bf16* row_ptr, const f32x16 (&acc)[A32<D>::NB], const float mul, const int hi) {
+__device__ __forceinline__ void store_rows32(bf16* row_ptr, const f32x16 (&acc)[A32<D>::NB], const float mul, const int hi, const bool ok) {
 #pragma unroll
   for (int blk = 0; blk < A32<D>::NB; ++blk)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const bf16x4 o = {(bf16)(acc[blk][4 * g + 0] * mul), (bf16)(acc[blk][4 * g + 1] * mul),
-                        (bf16)(acc[blk][4 * g + 2] * mul), (bf16)(acc[blk][4 * g + 3] * mul)};
-      *reinterpret_cast<bf16x4*>(row_ptr + 32 * blk + 8 * g + 4 * hi) = o;
+    for (int j = 0; j < 2; ++j) {
+      // a = group g = 2 j (registers 8 j .. 8 j + 3), b = group 2 j + 1 (registers 8 j + 4 .. 8 j + 7), two packed words each
+      unsigned a0 = pack_bf16x2(acc[blk][8 * j + 0] * mul, acc[blk][8 * j + 1] * mul);
+      unsigned a1 = pack_bf16x2(acc[blk][8 * j + 2] * mul, acc[blk][8 * j + 3] * mul);
+      unsigned b0 = pack_bf16x2(acc[blk][8 * j + 4] * mul, acc[blk][8 * j + 5] * mul);
+      unsigned b1 = pack_bf16x2(acc[blk][8 * j + 6] * mul, acc[blk][8 * j + 7] * mul);
+      // swap a's upper half-wave with b's lower half-wave: hi = 0 lanes then hold (own a, partner's a) = channels 16 j .. + 7,
+      // hi = 1 lanes (partner's b, own b) = channels 16 j + 8 .. + 15
+      const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+      const uint4 v = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+      if (ok) *reinterpret_cast<uint4*>(row_ptr + 32 * blk + 16 * j + 8 * hi) = v;
     }
 }
 
-// the text keys' partial dK_c^T / dV_c^T blocks of a wave -> the block's fp32 reduction buffer red[2][D][32] (LDS)
+// The text keys' partial dK_c^T / dV_c^T blocks of a wave -> its own fp32 slot [2][D][32] in LDS, with PLAIN stores: LDS float
+// atomics (ds_add_f32) into one shared buffer were measured at ~190 LDS cycles per wave-instruction -- 74 of the kernel's 84 M
+// LDS-busy cycles at L = 256, d = 96, and every other wave's fragment reads queued behind them (SQ_WAIT_INST_LDS 84 M
+// against 8 M without).
 template <int D>
-__device__ __forceinline__ void reduce_text32(float* red, const f32x16 (&dk)[A32<D>::NB], const f32x16 (&dv)[A32<D>::NB],
-                                              const int n, const int hi) {
+__device__ __forceinline__ void store_partial32(float* slot, const f32x16 (&dk)[A32<D>::NB], const f32x16 (&dv)[A32<D>::NB],
+                                                const int n, const int hi) {
 #pragma unroll
   for (int blk = 0; blk < A32<D>::NB; ++blk)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      atomicAdd(red + ch * 32 + n, dk[blk][r]);
-      atomicAdd(red + (D + ch) * 32 + n, dv[blk][r]);
+      slot[ch * 32 + n] = dk[blk][r];
+      slot[(D + ch) * 32 + n] = dv[blk][r];
     }
 }
-// ... and from there to dK_c / dV_c rows (whole block; `nthreads` threads)
+// ... and the sum of `nslot` slots -> dK_c / dV_c rows (whole block; `nthreads` threads)
 template <int D>
-__device__ __forceinline__ void store_text32(const float* red, const AttnArgs& p, const int b, const int h, const int S,
-                                             const int tid, const int nthreads) {
+__device__ __forceinline__ void store_text32(const float* slots, const int nslot, const AttnArgs& p, const int b, const int h,
+                                             const int S, const int tid, const int nthreads) {
   constexpr int CPR = A32<D>::CPR;
   for (int i = tid; i < 2 * 32 * CPR; i += nthreads) {
     const int t = i / (32 * CPR), rem_ = i - t * (32 * CPR);
     const int cc = rem_ / 32, key = rem_ - cc * 32;        // consecutive threads <-> consecutive keys: conflict-free LDS reads
     if (key >= S) continue;
     const float mul = t ? 1.f : p.scale;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int w = 0; w < nslot; ++w)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += slots[w * (2 * D * 32) + (t * D + cc * 8 + e) * 32 + key];
     bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16)(red[(t * D + cc * 8 + e) * 32 + key] * mul);
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)(acc[e] * mul);
     bf16* dst = reinterpret_cast<bf16*>(t ? p.dvc : p.dkc) + (size_t)b * p.dkc_bs + (size_t)h * D + (size_t)key * p.dkc_rs + cc * 8;
     *reinterpret_cast<bf16x8*>(dst) = o;
   }
@@ -287,6 +415,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, hi = lane >> 5;
   const Frag32Off<D> fo(lane);
+  // The second-dispatched half of an 8-wave block (waves 4-7) loses the issue arbitration against its SIMD partner on every
+  // segment (measured here: its tile loops run 40 % longer than those of waves 0-3, and every barrier waits for it): one
+  // static s_setprio for that half evens the two out (MI355X guide, "two waves per SIMD").
+  if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
   const int bh = xcd_remap((int)blockIdx.x, (int)gridDim.x);   // consecutive (batch, head) on one XCD: their rows share lines
   const int b = bh / p.H, h = bh - b * p.H;
   const bool has_c = p.kc != nullptr;
@@ -307,6 +439,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
   const RowSrc kcsrc(Kcp, has_c ? p.c_rs : p.k_rs, S), vcsrc(Vcp, has_c ? p.c_rs : p.k_rs, S);
 
   const unsigned tmask = has_c ? text_mask32(p, b, S, lane) : 0u;   // live text keys (wave-uniform bit mask)
+  // development aid (mdm_dev_set_attn_dbg): shader-clock stamps of the phases, [block][wave][16]
+#define ATT_STAMP(i)                                                                                                     \
+  if (p.dbg && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + (i)] = (unsigned long long)__builtin_amdgcn_s_memtime();
+  ATT_STAMP(0);
 
   // `rows` rows of a head view -> a swizzled image; chunk c of the call = row c / CPR, chunk c % CPR
   constexpr int NV = (256 * CPR + 511) / 512;
@@ -339,7 +475,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
     uint4 tc2 = uint4{0u, 0u, 0u, 0u};
     if (has_c) {
       // threads 0-255: chunks 0-255 of K_c, threads 256-511: of V_c; the remaining 32 CPR - 256 chunks in a second round
-      const RowSrc& ts = tid < 256 ? kcsrc : vcsrc;
+      const RowSrc& ts = __builtin_amdgcn_readfirstlane(tid) < 256 ? kcsrc : vcsrc;   // (wave-uniform: no waterfall loop)
       tc = ts.chunk(trow, tcc * 16);
       if (32 * CPR > 256) {
         const int c = 256 + (tid & 255);
@@ -348,10 +484,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
       }
     }
     stage_commit(R0, kv, nt * 32);
+    ATT_STAMP(1);
     stage_commit(R1, vv, nt * 32);
     stage_commit(R2, qv, nt * 32);
     if (has_c) {
-      char* timg = tid < 256 ? KC : VC;
+      char* timg = __builtin_amdgcn_readfirstlane(tid) < 256 ? KC : VC;
       *reinterpret_cast<uint4*>(timg + G::off(trow, tcc)) = tc;
       if (32 * CPR > 256) {
         const int c = 256 + (tid & 255);
@@ -382,38 +519,45 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
     if (hi == 0) {
       nlse_self[qi] = nls; nlse_cross[qi] = nlc; ndel_self[qi] = nds; ndel_cross[qi] = ndc;
     }
+    ATT_STAMP(2);
     __syncthreads();                         // (all 512 threads reach one of the two barriers of this if / else)
 
     f32x16 dq[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) dq[blk] = splat16(0.f);
     const int ntile = nt + (has_c ? 1 : 0);
+    Ops32<D, QPf<D>::value> ko;
+    load_ops32<D, QPf<D>::value>(ko, R0, R1, fo);       // tile 0 (the next tile's operands are read inside each step)
+    ATT_STAMP(3);
     for (int kt = 0; kt < ntile; ++kt) {
       const bool cross = kt >= nt;
       const char* Kt = cross ? KC : R0 + kt * T32;
+      const int kn = kt + 1 < ntile ? kt + 1 : kt;
       const char* Vt = cross ? VC : R1 + kt * T32;
+      const char* Kn = kn >= nt ? KC : R0 + kn * T32;
+      const char* Vn = kn >= nt ? VC : R1 + kn * T32;
       const int rem = L - kt * 32;
       const unsigned live = cross ? tmask : (rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u));
-      q_step32<D>(Kt, Vt, qf, gf, cross ? nlc : nls, cross ? ndc : nds, live, c2, hi, fo, dq);
+      q_step32<D>(ko, Kt, Vt, Kn, Vn, qf, gf, cross ? nlc : nls, cross ? ndc : nds, live, c2, hi, fo, dq);
     }
+    ATT_STAMP(4);
     // dQ^T: lane <-> query, register r <-> channel 32 blk + 8 (r >> 2) + 4 hi + (r & 3)
-    if (qok) store_rows32<D>(reinterpret_cast<T*>(p.dq) + (size_t)b * p.q_bs + (size_t)h * D + (size_t)qi * p.q_rs, dq, p.scale, hi);
+    store_rows32<D>(reinterpret_cast<T*>(p.dq) + (size_t)b * p.q_bs + (size_t)h * D + (size_t)(qok ? qi : 0) * p.q_rs, dq, p.scale, hi, qok);
   } else {
     __syncthreads();
   }
 
-  // ---- switch: dO -> R0, the reduction buffer of the text keys (R1) cleared ------------------------------------------
+  // ---- switch: dO -> R0 ---------------------------------------------------------------------------------------------------
+  ATT_STAMP(5);
   __syncthreads();                           // every wave is done with K, V, K_c, V_c
+  ATT_STAMP(6);
   {
     uint4 gv[NV];
     stage_fetch(gv, gsrc, nt * 32);
-    if (has_c) {
-      float* red = reinterpret_cast<float*>(R1);
-      for (int i = tid; i < 2 * D * 32; i += 512) red[i] = 0.f;
-    }
     stage_commit(R0, gv, nt * 32);
   }
   __syncthreads();
+  ATT_STAMP(7);
 
   // ---- phase K ----------------------------------------------------------------------------------------------------
   const int k0 = wave * 32;
@@ -428,32 +572,50 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
     f32x16 dk[NB], dv[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) { dk[blk] = splat16(0.f); dv[blk] = splat16(0.f); }
-    for (int qt = 0; qt < nt; ++qt)
-      k_step32<D>(R2 + qt * T32, R0 + qt * T32, nlse_self + qt * 32, ndel_self + qt * 32, kf, vf, key < L, c2, hi, fo, dk, dv);
-    if (key < L) {
-      const size_t ro = (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key * p.dk_rs;
-      store_rows32<D>(reinterpret_cast<T*>(p.dk) + ro, dk, p.scale, hi);
-      store_rows32<D>(reinterpret_cast<T*>(p.dv) + ro, dv, 1.f, hi);
+    Ops32<D, KPf<D>::value> qo;
+    load_ops32<D, KPf<D>::value>(qo, R2, R0, fo);
+    for (int qt = 0; qt < nt; ++qt) {
+      const int qn = qt + 1 < nt ? qt + 1 : qt;
+      k_step32<D>(qo, R2 + qt * T32, R0 + qt * T32, R2 + qn * T32, R0 + qn * T32, nlse_self + qt * 32, ndel_self + qt * 32,
+                  kf, vf, key < L, c2, hi, fo, dk, dv);
     }
+    ATT_STAMP(8);
+    {
+      const size_t ro = (size_t)b * p.dk_bs + (size_t)h * D + (size_t)(key < L ? key : 0) * p.dk_rs;
+      store_rows32<D>(reinterpret_cast<T*>(p.dk) + ro, dk, p.scale, hi, key < L);
+      store_rows32<D>(reinterpret_cast<T*>(p.dv) + ro, dv, 1.f, hi, key < L);
+    }
+    ATT_STAMP(9);
   }
   if (has_c) {
-    float* red = reinterpret_cast<float*>(R1);   // [2][D][32 keys]: dK_c^T, dV_c^T
-    if (q_active) {                              // this wave's query tile (index `wave`) against the text keys
-      bf16x8 kf[KS], vf[KS];
+    // The text keys: waves 0-3 take the query tiles w, w + 4 against them; their four partial [2][d][32] blocks go to LDS
+    // slots (the operand images are dead by then) and the whole block adds them up on the way out.
+    f32x16 dk[NB], dv[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) { dk[blk] = splat16(0.f); dv[blk] = splat16(0.f); }
+    if (wave < 4 && __builtin_amdgcn_readfirstlane(wave) < nt) {
+      bf16x8 kf[KS], vf[KS];                 // the text keys' operand fragments: their LDS images are still in place
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        kf[s] = kcsrc.frag(n, s, hi);
-        vf[s] = vcsrc.frag(n, s, hi);
+        kf[s] = lds_b128(KC + fo.b[s]);
+        vf[s] = lds_b128(VC + fo.b[s]);
       }
-      f32x16 dk[NB], dv[NB];
-#pragma unroll
-      for (int blk = 0; blk < NB; ++blk) { dk[blk] = splat16(0.f); dv[blk] = splat16(0.f); }
-      k_step32<D>(R2 + wave * T32, R0 + wave * T32, nlse_cross + wave * 32, ndel_cross + wave * 32, kf, vf,
-                  ((tmask >> n) & 1u) != 0u, c2, hi, fo, dk, dv);
-      reduce_text32<D>(red, dk, dv, n, hi);
+      Ops32<D, KPf<D>::value> qo;
+      load_ops32<D, KPf<D>::value>(qo, R2 + wave * T32, R0 + wave * T32, fo);
+      for (int qt = wave; qt < nt; qt += 4) {
+        const int qn = qt + 4 < nt ? qt + 4 : qt;
+        k_step32<D>(qo, R2 + qt * T32, R0 + qt * T32, R2 + qn * T32, R0 + qn * T32, nlse_cross + qt * 32, ndel_cross + qt * 32,
+                    kf, vf, ((tmask >> n) & 1u) != 0u, c2, hi, fo, dk, dv);
+      }
     }
+    ATT_STAMP(10);
+    __syncthreads();                         // nobody reads Q / dO any more
+    float* slots = reinterpret_cast<float*>(smem);   // [4][2][D][32] over R0, R1 (4 x 24 KB at d = 96)
+    if (wave < 4) store_partial32<D>(slots + wave * (2 * D * 32), dk, dv, n, hi);
+    ATT_STAMP(11);
     __syncthreads();
-    store_text32<D>(red, p, b, h, S, tid, 512);
+    store_text32<D>(slots, 4, p, b, h, S, tid, 512);
+    ATT_STAMP(12);
   }
 }
 
@@ -474,14 +636,17 @@ template <int D> struct Stream32 {
   static constexpr int HALF = 64 * G::PITCH;                 // one tensor's 64 rows
   static constexpr int NVS = 2 * 64 * G::CPR / 512;          // 16-byte chunks per thread and stage (two tensors)
   static_assert(2 * 64 * G::CPR % 512 == 0, "stage chunks divide over 512 threads");
-  // chunk i of thread tid: tensor (c / (64 CPR)), row, chunk
+  // chunk i of thread tid: tensor (c / (64 CPR)), row, chunk.  The tensor of a chunk is the same for a whole wave (64 CPR is a
+  // multiple of 64); saying so (readfirstlane) keeps the buffer descriptor in SGPRs -- a per-lane choice between two
+  // descriptors makes every load a waterfall loop
   static __device__ __forceinline__ void fetch(uint4 (&v)[NVS], const RowSrc& a, const RowSrc& b_, int row0, int tid) {
 #pragma unroll
     for (int i = 0; i < NVS; ++i) {
       const int c = tid + i * 512;
       const int which = c / (64 * G::CPR), c1 = c - which * (64 * G::CPR);
       const int row = c1 / G::CPR, cc = c1 - row * G::CPR;
-      v[i] = (which ? b_ : a).chunk(row0 + row, cc * 16);
+      if (__builtin_amdgcn_readfirstlane(which)) v[i] = b_.chunk(row0 + row, cc * 16);
+      else v[i] = a.chunk(row0 + row, cc * 16);
     }
   }
   static __device__ __forceinline__ void commit(char* stage, const uint4 (&v)[NVS], int tid) {
@@ -501,13 +666,14 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq32_kernel(AttnArgs p) {
   using G = A32<D>;
   using ST = Stream32<D>;
   constexpr int KS = G::KS, NB = G::NB, PITCH = G::PITCH, T32 = 32 * PITCH;
-  constexpr int STAGE = 2 * ST::HALF;
+  constexpr int STAGE = 2 * ST::HALF;                          // K rows | V rows of 64 keys; three stages in LDS
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, hi = lane >> 5;
   const Frag32Off<D> fo(lane);
+  if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);   // (see attn_bwd_small32_kernel)
   const int bx_ = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
   const int by = bx_ / (int)gridDim.x, bx = bx_ - by * (int)gridDim.x;
   const int b = by / p.H, h = by - b * p.H;
@@ -529,15 +695,25 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq32_kernel(AttnArgs p) {
 
   const int q0 = bx * 256 + wave * 32, qi = q0 + n;
   const bool w_active = __builtin_amdgcn_readfirstlane(q0) < L, qok = qi < L;
+  const int nself = (L + 63) >> 6, ntot = nself + (has_c ? 1 : 0);
+  // stage t = self keys 64 t .. 64 t + 63, or (t == nself) the text keys; its global loads
+  uint4 stg[ST::NVS];
+  auto fetch = [&](const int t) {
+    if (t < nself) ST::fetch(stg, ksrc, vsrc, t * 64, tid);
+    else ST::fetch(stg, kcsrc, vcsrc, 0, tid);
+  };
+  fetch(0);
   bf16x8 qf[KS], gf[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     qf[s] = qsrc.frag(qi, s, hi);
     gf[s] = gsrc.frag(qi, s, hi);
   }
-  const int nself = (L + 63) >> 6, ntot = nself + (has_c ? 1 : 0);
-  uint4 stg[ST::NVS];
-  ST::fetch(stg, ksrc, vsrc, 0, tid);
+  ST::commit(smem, stg, tid);
+  if (ntot > 1) {
+    fetch(1);
+    ST::commit(smem + STAGE, stg, tid);
+  }
   float a, c;
   delta32<D>(gf, osrc, Ocp, p.o_rs, qi, qok, hi, a, c);
   const size_t lo = ((size_t)b * p.H + h) * L + (qok ? qi : 0);
@@ -548,39 +724,47 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq32_kernel(AttnArgs p) {
   const float nls = qok ? -p.lse_self[lo] * inv_scale : -1e30f;
   const float nlc = (qok && has_c) ? -p.lse_cross[lo] * inv_scale : -1e30f;
   const float nds = qok ? -a : 0.f, ndc = qok ? -c : 0.f;
-  ST::commit(smem, stg, tid);
 
   f32x16 dq[NB];
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) dq[blk] = splat16(0.f);
-  // stage t out of LDS buffer CUR (compile-time: every fragment address is per-lane offset + immediate)
+  frags_arrived(qf);
+  frags_arrived(gf);
+  __syncthreads();                                             // stages 0 and 1 are in LDS
+  Ops32<D, QPf<D>::value> ko;
+  load_ops32<D, QPf<D>::value>(ko, smem, smem + ST::HALF, fo);
+  // Iteration t: stage t sits in buffer t % 3 and stage t + 1 in buffer (t + 1) % 3 (committed one iteration ago, visible
+  // since this iteration's barrier); stage t + 2 is fetched now and committed into buffer (t + 2) % 3 -- which every wave
+  // left before the barrier -- after the arithmetic.  So the last tile of a stage reads its successor's operands ahead
+  // like any other.  CUR is compile-time: fragment addresses are per-lane offset + immediate.
   auto stage = [&](auto cur_c, const int t) {
-    constexpr int CUR = decltype(cur_c)::value;
+    constexpr int CUR = decltype(cur_c)::value, NXT = (CUR + 1) % 3, NN = (CUR + 2) % 3;
     const char* Ks = smem + CUR * STAGE;
-    const char* Vs = Ks + ST::HALF;
     __syncthreads();
-    const bool more = t + 1 < ntot;
-    if (more) {
-      if (t + 1 < nself) ST::fetch(stg, ksrc, vsrc, (t + 1) * 64, tid);
-      else ST::fetch(stg, kcsrc, vcsrc, 0, tid);
-    }
+    const bool more = t + 2 < ntot;
+    if (more) fetch(t + 2);
     if (w_active) {
       const bool cross = t >= nself;
+      const int nsub = cross ? 1 : (L - t * 64 > 32 ? 2 : 1);
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        const int rem = cross ? 0 : L - (t * 64 + sub * 32);
-        const unsigned live = cross ? (sub == 0 ? tmask : 0u) : (rem >= 32 ? 0xffffffffu : (rem > 0 ? ((1u << rem) - 1u) : 0u));
-        if (live == 0u) continue;              // (wave-uniform) no key of this half takes part
-        q_step32<D>(Ks + sub * T32, Vs + sub * T32, qf, gf, cross ? nlc : nls, cross ? ndc : nds, live, c2, hi, fo, dq);
+        if (sub >= nsub) break;
+        const int rem = L - (t * 64 + sub * 32);
+        const unsigned live = cross ? tmask : (rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u));
+        // the next tile: the other half of this stage, else the first half of the next stage, else (nothing left) itself
+        const bool in_stage = sub + 1 < nsub, last = !in_stage && t + 1 >= ntot;
+        const char* Kn = in_stage ? Ks + T32 : (last ? Ks + sub * T32 : smem + NXT * STAGE);
+        q_step32<D>(ko, Ks + sub * T32, Ks + ST::HALF + sub * T32, Kn, Kn + ST::HALF, qf, gf, cross ? nlc : nls, cross ? ndc : nds, live, c2, hi, fo, dq);
       }
     }
-    if (more) ST::commit(smem + (1 - CUR) * STAGE, stg, tid);
+    if (more) ST::commit(smem + NN * STAGE, stg, tid);
   };
-  for (int t = 0; t < ntot; t += 2) {
+  for (int t = 0; t < ntot; t += 3) {
     stage(IntC<0>{}, t);
     if (t + 1 < ntot) stage(IntC<1>{}, t + 1);
+    if (t + 2 < ntot) stage(IntC<2>{}, t + 2);
   }
-  if (qok) store_rows32<D>(reinterpret_cast<T*>(p.dq) + (size_t)b * p.q_bs + (size_t)h * D + (size_t)qi * p.q_rs, dq, p.scale, hi);
+  store_rows32<D>(reinterpret_cast<T*>(p.dq) + (size_t)b * p.q_bs + (size_t)h * D + (size_t)(qok ? qi : 0) * p.q_rs, dq, p.scale, hi, qok);
 }
 
 template <int D>
@@ -588,7 +772,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
   using T = bf16;
   using G = A32<D>;
   using ST = Stream32<D>;
-  constexpr int KS = G::KS, NB = G::NB, CPR = G::CPR, PITCH = G::PITCH, T32 = 32 * PITCH;
+  constexpr int KS = G::KS, NB = G::NB, CPR = G::CPR, PITCH = G::PITCH, T32 = 32 * PITCH, PF = KPf<D>::value;
   constexpr int STAGE = 2 * ST::HALF + 512;                    // Q rows | dO rows | -lse / scale [64] | -delta [64]
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -596,6 +780,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, hi = lane >> 5;
   const Frag32Off<D> fo(lane);
+  if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);   // (see attn_bwd_small32_kernel)
   const int bx_ = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
   const int by = bx_ / (int)gridDim.x, bx = bx_ - by * (int)gridDim.x;
   const int b = by / p.H, h = by - b * p.H;
@@ -616,63 +801,78 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
     const RowSrc ksrc(Kp, p.k_rs, L), vsrc(Vp, p.k_rs, L);
     const int k0 = bx * 256 + wave * 32, key = k0 + n;
     const bool w_active = __builtin_amdgcn_readfirstlane(k0) < L;
+    const int nst = (L + 63) >> 6;
+    uint4 stg[ST::NVS];
+    // threads 0-63: lse, 64-127: delta of query 64 t + (tid & 63).  The RAW value is kept until the commit: arithmetic on it
+    // here would put an s_waitcnt vmcnt(0) -- a wait for the whole stage's global loads -- in front of the stage's MFMAs
+    float fl_r = 0.f;
+    bool fl_ok = false;
+    const float* const fl_src = (tid < 64 ? p.lse_self : p.delta_self) + lrow;
+    auto fetch = [&](const int t) {
+      ST::fetch(stg, qsrc, gsrc, t * 64, tid);
+      if (tid < 128) {
+        const int q = t * 64 + (tid & 63);
+        fl_ok = q < L;
+        fl_r = fl_src[fl_ok ? q : 0];
+      }
+    };
+    auto commit = [&](char* buf) {
+      ST::commit(buf, stg, tid);
+      if (tid < 128) {
+        const float v = tid < 64 ? (fl_ok ? -fl_r * inv_scale : -1e30f) : (fl_ok ? -fl_r : 0.f);
+        reinterpret_cast<float*>(buf + 2 * ST::HALF)[tid] = v;
+      }
+    };
+    fetch(0);
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       kf[s] = ksrc.frag(key, s, hi);
       vf[s] = vsrc.frag(key, s, hi);
     }
-    const int nst = (L + 63) >> 6;
-    uint4 stg[ST::NVS];
-    float fl_r = 0.f;                          // threads 0-63: -lse / scale, 64-127: -delta of query row0 + (tid & 63)
-    auto fetch_fl = [&](int row0) {
-      if (tid < 128) {
-        const int q = row0 + (tid & 63);
-        const bool ok = q < L;
-        if (tid < 64) fl_r = ok ? -p.lse_self[lrow + q] * inv_scale : -1e30f;
-        else fl_r = ok ? -p.delta_self[lrow + q] : 0.f;
-      }
-    };
-    ST::fetch(stg, qsrc, gsrc, 0, tid);
-    fetch_fl(0);
-    ST::commit(smem, stg, tid);
-    if (tid < 128) reinterpret_cast<float*>(smem + 2 * ST::HALF)[tid] = fl_r;
-
+    commit(smem);
+    if (nst > 1) {
+      fetch(1);
+      commit(smem + STAGE);
+    }
     f32x16 dk[NB], dv[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) { dk[blk] = splat16(0.f); dv[blk] = splat16(0.f); }
+    frags_arrived(kf);
+    frags_arrived(vf);
+    __syncthreads();
+    Ops32<D, PF> qo;
+    load_ops32<D, PF>(qo, smem, smem + ST::HALF, fo);
+    // (three LDS buffers, as in attn_bwd_dq32_kernel)
     auto stage = [&](auto cur_c, const int t) {
-      constexpr int CUR = decltype(cur_c)::value;
+      constexpr int CUR = decltype(cur_c)::value, NXT = (CUR + 1) % 3, NN = (CUR + 2) % 3;
       const char* Qs = smem + CUR * STAGE;
-      const char* Gs = Qs + ST::HALF;
       const float* nl = reinterpret_cast<const float*>(Qs + 2 * ST::HALF);
       __syncthreads();
-      const bool more = t + 1 < nst;
-      if (more) {
-        ST::fetch(stg, qsrc, gsrc, (t + 1) * 64, tid);
-        fetch_fl((t + 1) * 64);
-      }
+      const bool more = t + 2 < nst;
+      if (more) fetch(t + 2);
       if (w_active) {
+        const int nsub = L - t * 64 > 32 ? 2 : 1;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-          if (t * 64 + sub * 32 >= L) continue;   // (uniform) no query in this half
-          k_step32<D>(Qs + sub * T32, Gs + sub * T32, nl + sub * 32, nl + 64 + sub * 32, kf, vf, key < L, c2, hi, fo, dk, dv);
+          if (sub >= nsub) break;
+          const bool in_stage = sub + 1 < nsub, last = !in_stage && t + 1 >= nst;
+          const char* Qn = in_stage ? Qs + T32 : (last ? Qs + sub * T32 : smem + NXT * STAGE);
+          k_step32<D>(qo, Qs + sub * T32, Qs + ST::HALF + sub * T32, Qn, Qn + ST::HALF, nl + sub * 32, nl + 64 + sub * 32,
+                      kf, vf, key < L, c2, hi, fo, dk, dv);
         }
       }
-      if (more) {
-        char* nb = smem + (1 - CUR) * STAGE;
-        ST::commit(nb, stg, tid);
-        if (tid < 128) reinterpret_cast<float*>(nb + 2 * ST::HALF)[tid] = fl_r;
-      }
+      if (more) commit(smem + NN * STAGE);
     };
-    for (int t = 0; t < nst; t += 2) {
+    for (int t = 0; t < nst; t += 3) {
       stage(IntC<0>{}, t);
       if (t + 1 < nst) stage(IntC<1>{}, t + 1);
+      if (t + 2 < nst) stage(IntC<2>{}, t + 2);
     }
-    if (key < L) {
-      const size_t ro = (size_t)b * p.dk_bs + (size_t)h * D + (size_t)key * p.dk_rs;
-      store_rows32<D>(reinterpret_cast<T*>(p.dk) + ro, dk, p.scale, hi);
-      store_rows32<D>(reinterpret_cast<T*>(p.dv) + ro, dv, 1.f, hi);
+    {
+      const size_t ro = (size_t)b * p.dk_bs + (size_t)h * D + (size_t)(key < L ? key : 0) * p.dk_rs;
+      store_rows32<D>(reinterpret_cast<T*>(p.dk) + ro, dk, p.scale, hi, key < L);
+      store_rows32<D>(reinterpret_cast<T*>(p.dv) + ro, dv, 1.f, hi, key < L);
     }
     return;
   }
@@ -684,8 +884,6 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
   const unsigned tmask = text_mask32(p, b, S, lane);
   constexpr int PRIV = 2 * T32 + 256;                          // Q tile | dO tile | -lse / scale [32] | -delta [32]
   char* const mine = smem + wave * PRIV;
-  float* const red = reinterpret_cast<float*>(smem + 8 * PRIV);   // [2][D][32]
-  for (int i = tid; i < 2 * D * 32; i += 512) red[i] = 0.f;
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -723,20 +921,24 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const float* nl = reinterpret_cast<const float*>(mine + 2 * T32);
-    k_step32<D>(mine, mine + T32, nl, nl + 32, kf, vf, ((tmask >> n) & 1u) != 0u, c2, hi, fo, dk, dv);
+    Ops32<D, PF> qo;
+    load_ops32<D, PF>(qo, mine, mine + T32, fo);
+    k_step32<D>(qo, mine, mine + T32, mine, mine + T32, nl, nl + 32, kf, vf, ((tmask >> n) & 1u) != 0u, c2, hi, fo, dk, dv);
   }
-  __syncthreads();                                             // red is cleared
-  reduce_text32<D>(red, dk, dv, n, hi);
+  __syncthreads();                                             // the private tiles are dead: the slots overlay them
+  float* const slots = reinterpret_cast<float*>(smem);         // [8][2][D][32]
+  store_partial32<D>(slots + wave * (2 * D * 32), dk, dv, n, hi);
   __syncthreads();
-  store_text32<D>(red, p, b, h, S, tid, 512);
+  store_text32<D>(slots, 8, p, b, h, S, tid, 512);
 }
 
-template <int D> constexpr int attn_bwd_dq32_lds() { return 2 * 2 * 64 * 2 * D; }
+template <int D> constexpr int attn_bwd_dq32_lds() { return 3 * 2 * 64 * 2 * D; }
 template <int D> constexpr int attn_bwd_dkv32_lds() {
-  return (2 * (2 * 64 * 2 * D + 512)) > (8 * (2 * 32 * 2 * D + 256) + 2 * D * 32 * 4) ? (2 * (2 * 64 * 2 * D + 512))
-                                                                                      : (8 * (2 * 32 * 2 * D + 256) + 2 * D * 32 * 4);
+  constexpr int stages = 3 * (2 * 64 * 2 * D + 512), priv = 8 * (2 * 32 * 2 * D + 256), slots = 8 * 2 * D * 32 * 4;
+  return stages > priv ? (stages > slots ? stages : slots) : (priv > slots ? priv : slots);
 }
 
+#undef ATT_STAMP
 template <int D> constexpr int attn_bwd_small32_lds() { return 3 * 256 * 2 * D + 2 * 32 * 2 * D + 4096; }
 
 }  // namespace mdm

@@ -136,7 +136,59 @@ def timing(B=64):
         print(line, flush=True)
 
 
+def stamps(B=64, L=256, d=96):
+    """phase time stamps of attn_bwd_small32_kernel (mdm_dev_set_attn_dbg): shader cycles between the stamps, mean over blocks"""
+    C = 8 * d
+    qkv = torch.randn(B, L, 3 * C, device=dev).bfloat16().requires_grad_()
+    kvc = torch.randn(B, 32, 2 * C, device=dev).bfloat16().requires_grad_()
+    _lib.lib().mdm_dev_set_attn_bwd(2)
+    o = ops.attention(qkv, kvc, None, 8)
+    go = torch.randn_like(o)
+    torch.autograd.grad(o, (qkv, kvc), go, retain_graph=True)
+    buf = torch.zeros(B * 8, 8, 16, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    import ctypes
+    _lib.lib().mdm_dev_set_attn_dbg(ctypes.c_void_p(buf.data_ptr()))
+    torch.autograd.grad(o, (qkv, kvc), go, retain_graph=True)
+    torch.cuda.synchronize()
+    _lib.lib().mdm_dev_set_attn_dbg(None)
+    _lib.lib().mdm_dev_set_attn_bwd(0)
+    t = buf.cpu().double()
+    names = ["start", "K committed", "Q-phase operands + delta", "barrier + tile 0 operands", "Q loop", "dq stored", "barrier",
+             "dO staged + barrier", "K self loop", "dk / dv stored", "text step", "text reduce", "text stored"]
+    t0 = t[:, :, 0:1].min()
+    print("stamps B=%d L=%d d=%d: cycles since the previous stamp (mean over blocks; wave 0 | wave 7), start spread %.0f" %
+          (B, L, d, float(t[:, 0, 0].max() - t0)))
+    prev = t[:, :, 0]
+    for i in range(1, 13):
+        cur = t[:, :, i]
+        ok = cur > 0
+        dlt = (cur - prev)
+        print("   %-28s  %9.0f | %9.0f    (max %9.0f)" % (names[i], float(dlt[:, 0].mean()), float(dlt[:, 7].mean()), float(dlt.max())))
+        prev = torch.where(ok, cur, prev)
+    tot = t[:, :, 12] - t[:, :, 0]
+    print("   block total: mean %.0f cycles, max %.0f; first block start -> last block end %.0f" %
+          (float(tot.mean()), float(tot.max()), float(t[:, :, 12].max() - t0)))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "stamps":
+        stamps()
+        stamps(64, 256, 64)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pmc":      # a few launches of every backward path, for rocprofv3 --pmc
+        for L, d in ((256, 96), (1024, 64)):
+            C = 8 * d
+            qkv = torch.randn(64, L, 3 * C, device=dev).bfloat16().requires_grad_()
+            kvc = torch.randn(64, 32, 2 * C, device=dev).bfloat16().requires_grad_()
+            for mode in MODES:
+                _lib.lib().mdm_dev_set_attn_bwd(mode)
+                o = ops.attention(qkv, kvc, None, 8)
+                go = torch.randn_like(o)
+                for _ in range(3):
+                    torch.autograd.grad(o, (qkv, kvc), go, retain_graph=True)
+        torch.cuda.synchronize()
+        sys.exit(0)
     cases = [
         (2, 256, 32, 8, 96, False),
         (3, 256, 32, 8, 64, True),
