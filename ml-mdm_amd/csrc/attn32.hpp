@@ -124,6 +124,30 @@ struct RowSrc {
 //     |  the NEXT tile's S / dP operands issued  |  dQ (dV, dK) products.
 // LDS returns in order, so the waits hipcc inserts are counted (lgkmcnt(n)), not drains.
 #define MDM_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Issue priority of a wave for one tile step.  The two waves of a SIMD (waves w and w + 4 of a block) are arbitrated by
+// priority, then age: left alone, the second-dispatched half runs its tile loops 40 % longer (measured: 17.5 K against 12.3 K
+// cycles for the nine tiles of phase Q) and every barrier waits for it; a static s_setprio for that half only swaps the roles
+// (12.1 K / 17.2 K).  Alternating the priority tile by tile lets the pair take turns, so both halves finish together.
+#ifndef MDM_ATT_SR
+#define MDM_ATT_SR 64
+#endif
+#ifndef MDM_ATT_PRIO
+#define MDM_ATT_PRIO 0
+#endif
+// timing-only ablations of the streaming kernels (development: tools/build_variant.sh -DMDM_ATT_ABL=<bits>; results are wrong):
+// 1 no v_exp, 2 no transpose reads, 4 no barrier in the stage loops, 8 no fetch / commit in the stage loops, 16 no S / dP
+// products, 32 no dQ / dV / dK products
+#ifndef MDM_ATT_ABL
+#define MDM_ATT_ABL 0
+#endif
+#define MDM_EXP2(x) ((MDM_ATT_ABL & 1) ? (x) : __builtin_amdgcn_exp2f(x))
+__device__ __forceinline__ void prio_flip(int step_plus_half) {
+#if MDM_ATT_PRIO == 2
+  if (__builtin_amdgcn_readfirstlane(step_plus_half) & 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
 #ifndef MDM_QPF96
 #define MDM_QPF96 3
 #endif
@@ -166,11 +190,13 @@ __device__ __forceinline__ void q_step32(Ops32<D, QPf<D>::value>& o, const char*
   f32x16 sc, dp;
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
+    if (MDM_ATT_ABL & 16) { sc = zero; dp = zero; continue; }
     sc = mma32(o.x[s], qf[s], s == 0 ? zero : sc);
     dp = mma32(o.y[s], gf[s], s == 0 ? zero : dp);
   }
 #pragma unroll
   for (int s = PF; s < G::KS; ++s) {
+    if (MDM_ATT_ABL & 16) continue;
     sc = mma32(xr[s - PF], qf[s], sc);
     dp = mma32(yr[s - PF], gf[s], dp);
   }
@@ -180,17 +206,17 @@ __device__ __forceinline__ void q_step32(Ops32<D, QPf<D>::value>& o, const char*
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
     for (int blk = 0; blk < G::NB; ++blk)
-      tk[s2][blk] = lds_tr_pair(Kt + s2 * 16 * G::PITCH + fo.tr[0][blk], Kt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
+      tk[s2][blk] = (MDM_ATT_ABL & 2) ? o.x[blk] : lds_tr_pair(Kt + s2 * 16 * G::PITCH + fo.tr[0][blk], Kt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
   MDM_FENCE();
   const float nl2 = nl * c2;
   if (live == 0xffffffffu) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, nl2)) * (dp[r] + nd);
+    for (int r = 0; r < 16; ++r) sc[r] = MDM_EXP2(fmaf(sc[r], c2, nl2)) * (dp[r] + nd);
   } else {
     const unsigned lv = live >> (4 * hi);    // this lane's registers hold keys (r & 3) + 8 (r >> 2) + 4 hi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pr = ((lv >> ((r & 3) + 8 * (r >> 2))) & 1u) ? __builtin_amdgcn_exp2f(fmaf(sc[r], c2, nl2)) : 0.f;
+      const float pr = ((lv >> ((r & 3) + 8 * (r >> 2))) & 1u) ? MDM_EXP2(fmaf(sc[r], c2, nl2)) : 0.f;
       sc[r] = pr * (dp[r] + nd);
     }
   }
@@ -199,9 +225,9 @@ __device__ __forceinline__ void q_step32(Ops32<D, QPf<D>::value>& o, const char*
   load_ops32<D, PF>(o, Kn, Vn, fo);
   MDM_FENCE();
 #pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) dq[blk] = mma32(tk[0][blk], ds0, dq[blk]);
+  for (int blk = 0; blk < G::NB; ++blk) if (!(MDM_ATT_ABL & 32)) dq[blk] = mma32(tk[0][blk], ds0, dq[blk]); else dq[blk][0] += (float)ds0[0] + (float)tk[0][blk][0];
 #pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) dq[blk] = mma32(tk[1][blk], ds1, dq[blk]);
+  for (int blk = 0; blk < G::NB; ++blk) if (!(MDM_ATT_ABL & 32)) dq[blk] = mma32(tk[1][blk], ds1, dq[blk]); else dq[blk][1] += (float)ds1[0] + (float)tk[1][blk][0];
 }
 
 // One 32-query tile for a wave that owns 32 keys (lane <-> key).  Qt / Gt: the tile's rows of Q / dO in swizzled images; o:
@@ -234,11 +260,13 @@ __device__ __forceinline__ void k_step32(Ops32<D, KPf<D>::value>& o, const char*
   }
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
+    if (MDM_ATT_ABL & 16) continue;
     sc = mma32(o.x[s], kf[s], sc);
     dp = mma32(o.y[s], vf[s], dp);
   }
 #pragma unroll
   for (int s = PF; s < G::KS; ++s) {
+    if (MDM_ATT_ABL & 16) continue;
     sc = mma32(xr[s - PF], kf[s], sc);
     dp = mma32(yr[s - PF], vf[s], dp);
   }
@@ -248,11 +276,11 @@ __device__ __forceinline__ void k_step32(Ops32<D, KPf<D>::value>& o, const char*
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
     for (int blk = 0; blk < G::NB; ++blk)
-      tg[s2][blk] = lds_tr_pair(Gt + s2 * 16 * G::PITCH + fo.tr[0][blk], Gt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
+      tg[s2][blk] = (MDM_ATT_ABL & 2) ? o.y[blk] : lds_tr_pair(Gt + s2 * 16 * G::PITCH + fo.tr[0][blk], Gt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
   MDM_FENCE();
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float pr = key_live ? __builtin_amdgcn_exp2f(sc[r] * c2) : 0.f;
+    const float pr = key_live ? MDM_EXP2(sc[r] * c2) : 0.f;
     sc[r] = pr;
     dp[r] = pr * dp[r];
   }
@@ -263,19 +291,19 @@ __device__ __forceinline__ void k_step32(Ops32<D, KPf<D>::value>& o, const char*
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
     for (int blk = 0; blk < G::NB; ++blk)
-      tq[s2][blk] = lds_tr_pair(Qt + s2 * 16 * G::PITCH + fo.tr[0][blk], Qt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
+      tq[s2][blk] = (MDM_ATT_ABL & 2) ? kf[blk] : lds_tr_pair(Qt + s2 * 16 * G::PITCH + fo.tr[0][blk], Qt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
   MDM_FENCE();
 #pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) dv[blk] = mma32(tg[0][blk], p0, dv[blk]);
+  for (int blk = 0; blk < G::NB; ++blk) if (!(MDM_ATT_ABL & 32)) dv[blk] = mma32(tg[0][blk], p0, dv[blk]); else dv[blk][0] += (float)p0[0] + (float)tg[0][blk][0];
 #pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) dv[blk] = mma32(tg[1][blk], p1, dv[blk]);
+  for (int blk = 0; blk < G::NB; ++blk) if (!(MDM_ATT_ABL & 32)) dv[blk] = mma32(tg[1][blk], p1, dv[blk]); else dv[blk][1] += (float)p1[0] + (float)tg[1][blk][0];
   MDM_FENCE();
   load_ops32<D, PF>(o, Qn, Gn, fo);
   MDM_FENCE();
 #pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) dk[blk] = mma32(tq[0][blk], s0, dk[blk]);
+  for (int blk = 0; blk < G::NB; ++blk) if (!(MDM_ATT_ABL & 32)) dk[blk] = mma32(tq[0][blk], s0, dk[blk]); else dk[blk][0] += (float)s0[0] + (float)tq[0][blk][0];
 #pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) dk[blk] = mma32(tq[1][blk], s1, dk[blk]);
+  for (int blk = 0; blk < G::NB; ++blk) if (!(MDM_ATT_ABL & 32)) dk[blk] = mma32(tq[1][blk], s1, dk[blk]); else dk[blk][1] += (float)s1[0] + (float)tq[1][blk][0];
 }
 
 // a wave's [d][32] accumulator block (lane <-> row of the tensor, register <-> channel) -> bf16 rows in global memory.
@@ -415,10 +443,6 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, hi = lane >> 5;
   const Frag32Off<D> fo(lane);
-  // The second-dispatched half of an 8-wave block (waves 4-7) loses the issue arbitration against its SIMD partner on every
-  // segment (measured here: its tile loops run 40 % longer than those of waves 0-3, and every barrier waits for it): one
-  // static s_setprio for that half evens the two out (MI355X guide, "two waves per SIMD").
-  if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
   const int bh = xcd_remap((int)blockIdx.x, (int)gridDim.x);   // consecutive (batch, head) on one XCD: their rows share lines
   const int b = bh / p.H, h = bh - b * p.H;
   const bool has_c = p.kc != nullptr;
@@ -538,6 +562,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
       const char* Vn = kn >= nt ? VC : R1 + kn * T32;
       const int rem = L - kt * 32;
       const unsigned live = cross ? tmask : (rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u));
+      prio_flip(kt + (wave >> 2));
       q_step32<D>(ko, Kt, Vt, Kn, Vn, qf, gf, cross ? nlc : nls, cross ? ndc : nds, live, c2, hi, fo, dq);
     }
     ATT_STAMP(4);
@@ -576,6 +601,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
     load_ops32<D, KPf<D>::value>(qo, R2, R0, fo);
     for (int qt = 0; qt < nt; ++qt) {
       const int qn = qt + 1 < nt ? qt + 1 : qt;
+      prio_flip(qt + (wave >> 2));
       k_step32<D>(qo, R2 + qt * T32, R0 + qt * T32, R2 + qn * T32, R0 + qn * T32, nlse_self + qt * 32, ndel_self + qt * 32,
                   kf, vf, key < L, c2, hi, fo, dk, dv);
     }
@@ -624,26 +650,29 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
 //
 // attn_bwd_dq32_kernel   block = 256 queries of one (batch, head), 8 waves x 32 queries (Q, dO operand fragments, lse, delta in
 //   registers; delta = rowsum(dO o O) is computed here and stored for the dK / dV kernel).  The keys stream through LDS in
-//   stages of 64 (K and V rows, double-buffered: the next stage's global loads are in flight during this stage's MFMAs and
-//   are committed after them; one barrier per stage); the text keys are one more stage.
+//   stages of 128 (K and V rows; three LDS buffers: the stage after next is fetched during this stage's MFMAs and committed
+//   after them, so a tile can read its successor's operands ahead even across a stage boundary; one barrier per stage);
+//   the text keys are one more stage.
 // attn_bwd_dkv32_kernel  block = 256 keys, 8 waves x 32 keys (K, V operand fragments in registers); the queries stream
-//   through LDS in stages of 64 (Q and dO rows + their -lse / scale and -delta).  The text keys of a (batch, head) are ONE
+//   through LDS in stages of 128 (Q and dO rows + their -lse / scale and -delta).  The text keys of a (batch, head) are ONE
 //   more block whose waves each take every 8th 32-query tile (staged privately per wave: no block barrier in that loop)
 //   and sum their partial dK_c^T / dV_c^T in LDS.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int D> struct Stream32 {
   using G = A32<D>;
-  static constexpr int HALF = 64 * G::PITCH;                 // one tensor's 64 rows
-  static constexpr int NVS = 2 * 64 * G::CPR / 512;          // 16-byte chunks per thread and stage (two tensors)
-  static_assert(2 * 64 * G::CPR % 512 == 0, "stage chunks divide over 512 threads");
-  // chunk i of thread tid: tensor (c / (64 CPR)), row, chunk.  The tensor of a chunk is the same for a whole wave (64 CPR is a
+  static constexpr int SR = MDM_ATT_SR;                      // rows (keys / queries) of a stage: SR / 32 tiles per barrier
+  static constexpr int NSUB = SR / 32;
+  static constexpr int HALF = SR * G::PITCH;                 // one tensor's rows
+  static constexpr int NVS = 2 * SR * G::CPR / 512;          // 16-byte chunks per thread and stage (two tensors)
+  static_assert(2 * SR * G::CPR % 512 == 0, "stage chunks divide over 512 threads");
+  // chunk i of thread tid: tensor (c / (SR CPR)), row, chunk.  The tensor of a chunk is the same for a whole wave (SR CPR is a
   // multiple of 64); saying so (readfirstlane) keeps the buffer descriptor in SGPRs -- a per-lane choice between two
   // descriptors makes every load a waterfall loop
   static __device__ __forceinline__ void fetch(uint4 (&v)[NVS], const RowSrc& a, const RowSrc& b_, int row0, int tid) {
 #pragma unroll
     for (int i = 0; i < NVS; ++i) {
       const int c = tid + i * 512;
-      const int which = c / (64 * G::CPR), c1 = c - which * (64 * G::CPR);
+      const int which = c / (SR * G::CPR), c1 = c - which * (SR * G::CPR);
       const int row = c1 / G::CPR, cc = c1 - row * G::CPR;
       if (__builtin_amdgcn_readfirstlane(which)) v[i] = b_.chunk(row0 + row, cc * 16);
       else v[i] = a.chunk(row0 + row, cc * 16);
@@ -653,7 +682,7 @@ template <int D> struct Stream32 {
 #pragma unroll
     for (int i = 0; i < NVS; ++i) {
       const int c = tid + i * 512;
-      const int which = c / (64 * G::CPR), c1 = c - which * (64 * G::CPR);
+      const int which = c / (SR * G::CPR), c1 = c - which * (SR * G::CPR);
       const int row = c1 / G::CPR, cc = c1 - row * G::CPR;
       *reinterpret_cast<uint4*>(stage + which * HALF + G::off(row, cc)) = v[i];
     }
@@ -666,14 +695,13 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq32_kernel(AttnArgs p) {
   using G = A32<D>;
   using ST = Stream32<D>;
   constexpr int KS = G::KS, NB = G::NB, PITCH = G::PITCH, T32 = 32 * PITCH;
-  constexpr int STAGE = 2 * ST::HALF;                          // K rows | V rows of 64 keys; three stages in LDS
+  constexpr int STAGE = 2 * ST::HALF, SR = ST::SR, NSUB = ST::NSUB;   // K rows | V rows of SR keys; three stages in LDS
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, hi = lane >> 5;
   const Frag32Off<D> fo(lane);
-  if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);   // (see attn_bwd_small32_kernel)
   const int bx_ = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
   const int by = bx_ / (int)gridDim.x, bx = bx_ - by * (int)gridDim.x;
   const int b = by / p.H, h = by - b * p.H;
@@ -695,11 +723,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq32_kernel(AttnArgs p) {
 
   const int q0 = bx * 256 + wave * 32, qi = q0 + n;
   const bool w_active = __builtin_amdgcn_readfirstlane(q0) < L, qok = qi < L;
-  const int nself = (L + 63) >> 6, ntot = nself + (has_c ? 1 : 0);
-  // stage t = self keys 64 t .. 64 t + 63, or (t == nself) the text keys; its global loads
+  const int nself = (L + SR - 1) / SR, ntot = nself + (has_c ? 1 : 0);
+  // stage t = self keys SR t .. SR t + SR - 1, or (t == nself) the text keys; its global loads
   uint4 stg[ST::NVS];
   auto fetch = [&](const int t) {
-    if (t < nself) ST::fetch(stg, ksrc, vsrc, t * 64, tid);
+    if (t < nself) ST::fetch(stg, ksrc, vsrc, t * SR, tid);
     else ST::fetch(stg, kcsrc, vcsrc, 0, tid);
   };
   fetch(0);
@@ -740,21 +768,23 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq32_kernel(AttnArgs p) {
   auto stage = [&](auto cur_c, const int t) {
     constexpr int CUR = decltype(cur_c)::value, NXT = (CUR + 1) % 3, NN = (CUR + 2) % 3;
     const char* Ks = smem + CUR * STAGE;
-    __syncthreads();
-    const bool more = t + 2 < ntot;
+    if (!(MDM_ATT_ABL & 4)) __syncthreads();
+    const bool more = t + 2 < ntot && !(MDM_ATT_ABL & 8);
     if (more) fetch(t + 2);
     if (w_active) {
       const bool cross = t >= nself;
-      const int nsub = cross ? 1 : (L - t * 64 > 32 ? 2 : 1);
+      const int nsub = cross ? 1 : min(NSUB, (L - t * SR + 31) >> 5);
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
+      for (int sub = 0; sub < NSUB; ++sub) {
         if (sub >= nsub) break;
-        const int rem = L - (t * 64 + sub * 32);
+        prio_flip(t * NSUB + sub + (wave >> 2));
+        const int rem = L - (t * SR + sub * 32);
         const unsigned live = cross ? tmask : (rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u));
-        // the next tile: the other half of this stage, else the first half of the next stage, else (nothing left) itself
+        // the next tile: the next tile of this stage, else the first of the next stage, else (nothing left) itself
         const bool in_stage = sub + 1 < nsub, last = !in_stage && t + 1 >= ntot;
-        const char* Kn = in_stage ? Ks + T32 : (last ? Ks + sub * T32 : smem + NXT * STAGE);
-        q_step32<D>(ko, Ks + sub * T32, Ks + ST::HALF + sub * T32, Kn, Kn + ST::HALF, qf, gf, cross ? nlc : nls, cross ? ndc : nds, live, c2, hi, fo, dq);
+        const char* Kn = in_stage ? Ks + (sub + 1) * T32 : (last ? Ks + sub * T32 : smem + NXT * STAGE);
+        q_step32<D>(ko, Ks + sub * T32, Ks + ST::HALF + sub * T32, Kn, Kn + ST::HALF, qf, gf, cross ? nlc : nls, cross ? ndc : nds,
+                    live, c2, hi, fo, dq);
       }
     }
     if (more) ST::commit(smem + NN * STAGE, stg, tid);
@@ -773,14 +803,14 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
   using G = A32<D>;
   using ST = Stream32<D>;
   constexpr int KS = G::KS, NB = G::NB, CPR = G::CPR, PITCH = G::PITCH, T32 = 32 * PITCH, PF = KPf<D>::value;
-  constexpr int STAGE = 2 * ST::HALF + 512;                    // Q rows | dO rows | -lse / scale [64] | -delta [64]
+  constexpr int SR = ST::SR, NSUB = ST::NSUB;
+  constexpr int STAGE = 2 * ST::HALF + 8 * SR;                 // Q rows | dO rows | -lse / scale [SR] | -delta [SR]
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, hi = lane >> 5;
   const Frag32Off<D> fo(lane);
-  if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);   // (see attn_bwd_small32_kernel)
   const int bx_ = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
   const int by = bx_ / (int)gridDim.x, bx = bx_ - by * (int)gridDim.x;
   const int b = by / p.H, h = by - b * p.H;
@@ -801,25 +831,25 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
     const RowSrc ksrc(Kp, p.k_rs, L), vsrc(Vp, p.k_rs, L);
     const int k0 = bx * 256 + wave * 32, key = k0 + n;
     const bool w_active = __builtin_amdgcn_readfirstlane(k0) < L;
-    const int nst = (L + 63) >> 6;
+    const int nst = (L + SR - 1) / SR;
     uint4 stg[ST::NVS];
-    // threads 0-63: lse, 64-127: delta of query 64 t + (tid & 63).  The RAW value is kept until the commit: arithmetic on it
+    // threads 0 .. SR-1: lse, SR .. 2 SR - 1: delta of query SR t + (tid % SR).  The RAW value is kept until the commit: arithmetic on it
     // here would put an s_waitcnt vmcnt(0) -- a wait for the whole stage's global loads -- in front of the stage's MFMAs
     float fl_r = 0.f;
     bool fl_ok = false;
-    const float* const fl_src = (tid < 64 ? p.lse_self : p.delta_self) + lrow;
+    const float* const fl_src = (tid < SR ? p.lse_self : p.delta_self) + lrow;
     auto fetch = [&](const int t) {
-      ST::fetch(stg, qsrc, gsrc, t * 64, tid);
-      if (tid < 128) {
-        const int q = t * 64 + (tid & 63);
+      ST::fetch(stg, qsrc, gsrc, t * SR, tid);
+      if (tid < 2 * SR) {
+        const int q = t * SR + (tid & (SR - 1));
         fl_ok = q < L;
         fl_r = fl_src[fl_ok ? q : 0];
       }
     };
     auto commit = [&](char* buf) {
       ST::commit(buf, stg, tid);
-      if (tid < 128) {
-        const float v = tid < 64 ? (fl_ok ? -fl_r * inv_scale : -1e30f) : (fl_ok ? -fl_r : 0.f);
+      if (tid < 2 * SR) {
+        const float v = tid < SR ? (fl_ok ? -fl_r * inv_scale : -1e30f) : (fl_ok ? -fl_r : 0.f);
         reinterpret_cast<float*>(buf + 2 * ST::HALF)[tid] = v;
       }
     };
@@ -848,17 +878,18 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
       constexpr int CUR = decltype(cur_c)::value, NXT = (CUR + 1) % 3, NN = (CUR + 2) % 3;
       const char* Qs = smem + CUR * STAGE;
       const float* nl = reinterpret_cast<const float*>(Qs + 2 * ST::HALF);
-      __syncthreads();
-      const bool more = t + 2 < nst;
+      if (!(MDM_ATT_ABL & 4)) __syncthreads();
+      const bool more = t + 2 < nst && !(MDM_ATT_ABL & 8);
       if (more) fetch(t + 2);
       if (w_active) {
-        const int nsub = L - t * 64 > 32 ? 2 : 1;
+        const int nsub = min(NSUB, (L - t * SR + 31) >> 5);
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
           if (sub >= nsub) break;
+          prio_flip(t * NSUB + sub + (wave >> 2));
           const bool in_stage = sub + 1 < nsub, last = !in_stage && t + 1 >= nst;
-          const char* Qn = in_stage ? Qs + T32 : (last ? Qs + sub * T32 : smem + NXT * STAGE);
-          k_step32<D>(qo, Qs + sub * T32, Qs + ST::HALF + sub * T32, Qn, Qn + ST::HALF, nl + sub * 32, nl + 64 + sub * 32,
+          const char* Qn = in_stage ? Qs + (sub + 1) * T32 : (last ? Qs + sub * T32 : smem + NXT * STAGE);
+          k_step32<D>(qo, Qs + sub * T32, Qs + ST::HALF + sub * T32, Qn, Qn + ST::HALF, nl + sub * 32, nl + SR + sub * 32,
                       kf, vf, key < L, c2, hi, fo, dk, dv);
         }
       }
@@ -932,9 +963,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
   store_text32<D>(slots, 8, p, b, h, S, tid, 512);
 }
 
-template <int D> constexpr int attn_bwd_dq32_lds() { return 3 * 2 * 64 * 2 * D; }
+template <int D> constexpr int attn_bwd_dq32_lds() { return 3 * 2 * Stream32<D>::SR * 2 * D; }
 template <int D> constexpr int attn_bwd_dkv32_lds() {
-  constexpr int stages = 3 * (2 * 64 * 2 * D + 512), priv = 8 * (2 * 32 * 2 * D + 256), slots = 8 * 2 * D * 32 * 4;
+  constexpr int stages = 3 * (2 * Stream32<D>::SR * 2 * D + 8 * Stream32<D>::SR), priv = 8 * (2 * 32 * 2 * D + 256), slots = 8 * 2 * D * 32 * 4;
   return stages > priv ? (stages > slots ? stages : slots) : (priv > slots ? priv : slots);
 }
 

@@ -172,6 +172,9 @@ def stamps(B=64, L=256, d=96):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "timeonly":
+        timing(int(os.environ.get("KB_BATCH", "64")))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stamps":
         stamps()
         stamps(64, 256, 64)
