@@ -141,6 +141,7 @@ struct RowSrc {
 #ifndef MDM_ATT_ABL
 #define MDM_ATT_ABL 0
 #endif
+
 #define MDM_EXP2(x) ((MDM_ATT_ABL & 1) ? (x) : __builtin_amdgcn_exp2f(x))
 __device__ __forceinline__ void prio_flip(int step_plus_half) {
 #if MDM_ATT_PRIO == 2
@@ -210,8 +211,17 @@ __device__ __forceinline__ void q_step32(Ops32<D, QPf<D>::value>& o, const char*
   MDM_FENCE();
   const float nl2 = nl * c2;
   if (live == 0xffffffffu) {
+    // two scores per instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32; only v_exp_f32 is per element): the loops of
+    // these kernels sit on their VALU floor -- with every MFMA, barrier and fetch removed the L = 1024 pair still takes 38 %
+    // of its time (profiles/r05_attn32_ablations.txt)
+    const f32x2 c2v = {c2, c2}, nlv = {nl2, nl2}, ndv = {nd, nd};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = MDM_EXP2(fmaf(sc[r], c2, nl2)) * (dp[r] + nd);
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 e = f32x2{sc[r], sc[r + 1]} * c2v + nlv;
+      const f32x2 pr = {MDM_EXP2(e[0]), MDM_EXP2(e[1])};
+      const f32x2 ds = pr * (f32x2{dp[r], dp[r + 1]} + ndv);
+      sc[r] = ds[0]; sc[r + 1] = ds[1];
+    }
   } else {
     const unsigned lv = live >> (4 * hi);    // this lane's registers hold keys (r & 3) + 8 (r >> 2) + 4 hi
 #pragma unroll
@@ -278,11 +288,23 @@ __device__ __forceinline__ void k_step32(Ops32<D, KPf<D>::value>& o, const char*
     for (int blk = 0; blk < G::NB; ++blk)
       tg[s2][blk] = (MDM_ATT_ABL & 2) ? o.y[blk] : lds_tr_pair(Gt + s2 * 16 * G::PITCH + fo.tr[0][blk], Gt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
   MDM_FENCE();
+  if (__builtin_amdgcn_readfirstlane(__all(key_live))) {   // (the common case: no select per score; packed as in q_step32)
+    const f32x2 c2v = {c2, c2};
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float pr = key_live ? MDM_EXP2(sc[r] * c2) : 0.f;
-    sc[r] = pr;
-    dp[r] = pr * dp[r];
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 e = f32x2{sc[r], sc[r + 1]} * c2v;
+      const f32x2 pr = {MDM_EXP2(e[0]), MDM_EXP2(e[1])};
+      const f32x2 ds = pr * f32x2{dp[r], dp[r + 1]};
+      sc[r] = pr[0]; sc[r + 1] = pr[1];
+      dp[r] = ds[0]; dp[r + 1] = ds[1];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = key_live ? MDM_EXP2(sc[r] * c2) : 0.f;
+      sc[r] = pr;
+      dp[r] = pr * dp[r];
+    }
   }
   const bf16x8 p0 = pack8(sc, 0), p1 = pack8(sc, 1), s0 = pack8(dp, 0), s1 = pack8(dp, 1);
   MDM_FENCE();
