@@ -181,6 +181,12 @@ def make_step(pipe, bf16, world, plain=False, bucket_mb=256.0, wire="auto", seri
     return step, opt
 
 
+def _binary_provenance():
+    """the library these numbers were measured on: path, SHA-256 of the loaded file, the git revision it was built from"""
+    from mdm_hip import _lib
+    return _lib.provenance()
+
+
 def timed_steps(step, sample, warmup, steps, sync):
     for _ in range(warmup):
         step(sample)
@@ -278,11 +284,14 @@ def main():
     assert getattr(opt, "_mdm_fused", False) not in (None, False), getattr(opt, "_mdm_fused_reason", "the fused path did not engage")
     # what went over the wire, and when: per bucket of the LAST step (bucket, MB, issued at, compute stream free at; ms from
     # the first bucket's issue) -- how much of the gradient exchange hid behind backward on this node
-    comm_wire, comm_timeline = "fp32", None
+    comm_wire, comm_timeline, comm_window = "fp32", None, None
     red = getattr(pipe.model, "reducer", None)
     if red is not None:
         comm_wire = "bf16" if red.wire_dtype == torch.bfloat16 else "fp32"
         comm_timeline = [[b, round(nb / 1e6, 1), round(t0, 3), round(t1, 3)] for b, nb, t0, t1 in red.timeline()]
+        win = red.backward_window_ms()
+        if win is not None:   # where the bucket times (relative to the first issue) sit inside the backward pass
+            comm_window = {"first_issue_ms_after_backward_start": round(win[0], 3), "backward_ms": round(win[1], 3)}
     if world > 1:
         tt = torch.tensor([dt], device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -498,7 +507,7 @@ def main():
                 "step_mfma_roofline_frac": round(alg_tflop_step / (ms / 1e3) / (PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS), 4),
                 "comm": {"backend": dist.get_backend() if dist.is_initialized() else None, "world_size": world, "forced_collectives": bool(args.force_collectives),
                          "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.is_initialized() else None,
-                         "bucket_mb": args.bucket_mb, "wire_dtype": comm_wire, "bucket_timeline_ms": comm_timeline},
+                         "bucket_mb": args.bucket_mb, "wire_dtype": comm_wire, "bucket_timeline_ms": comm_timeline, "backward_window": comm_window},
             },
             "roofline": roof,
             "sampling": samp,
@@ -506,6 +515,7 @@ def main():
             "reference_loop": ref_loop,
             "nested1024_sampling": n1024,
             "entry_point": "mdm_hip.trainer.train_batch (reference trainer.py:13-25 signature) on torch AdamW + LambdaLR + ModelEma objects, fused arena path",
+            "binary": _binary_provenance(),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, batch)

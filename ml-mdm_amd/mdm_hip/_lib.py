@@ -61,7 +61,42 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise MdmHipError("link failed:\n" + r.stdout.decode(errors="replace"))
+    _write_build_note(deps)
     return LIB_PATH
+
+
+def _write_build_note(deps):
+    """<lib>.build.json next to the library: what it was built from (git revision + a hash of every source it depends on).
+    The .so is git-ignored but ships to the GPU box, where there is no .git: provenance() reads this note there."""
+    import hashlib
+    import json
+    h = hashlib.sha256()
+    for d in sorted(deps):
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    def git(*a):
+        try:
+            return subprocess.run(["git", "-C", _ROOT] + list(a), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip()
+        except OSError:
+            return ""
+    note = {"git_describe": git("describe", "--always", "--dirty", "--abbrev=12"), "sources_sha256": h.hexdigest()}
+    with open(LIB_PATH + ".build.json", "w") as f:
+        json.dump(note, f)
+
+
+def provenance():
+    """{"lib", "sha256" (of the loaded .so), "git_describe", "sources_sha256" (from the build note, if present)} -- printed by
+    bench.py and __graft_entry__.smoke() so that a GPUTEST / BENCH record names the binary it ran"""
+    import hashlib
+    import json
+    out = {"lib": os.path.relpath(LIB_PATH, _ROOT), "sha256": None, "git_describe": None, "sources_sha256": None}
+    try:
+        out["sha256"] = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()
+        note = json.load(open(LIB_PATH + ".build.json"))
+        out["git_describe"], out["sources_sha256"] = note.get("git_describe"), note.get("sources_sha256")
+    except (OSError, ValueError):
+        pass
+    return out
 
 
 _CTYPES = {

@@ -12,15 +12,22 @@ torch DDP's reducer with a design sized for 8 x MI355X on point-to-point xGMI li
     backward produces gradients (reverse registration), so the first all-reduce starts while
     most of backward is still running;
   * a bucket's all-reduce is issued from a post-accumulate-grad hook as soon as its last
-    gradient is ready, asynchronously on RCCL's own stream; ``finish()`` joins before the
-    optimizer.  Optional bf16 wire format halves the bytes;
+    gradient is ready, asynchronously: a dedicated COMMUNICATION stream waits for an event recorded
+    on every stream that produced gradients of the bucket (main backward chain, weight-gradient side
+    stream) and hands the bucket to RCCL; no compute stream ever waits for another one on the
+    reducer's account (round 4 made the reporting stream wait for all producers: when that was the
+    main stream it stalled behind the whole backlog of the side stream).  ``finish()`` joins before
+    the optimizer.  Optional bf16 wire format halves the bytes;
   * the LAST bucket (the first layers of the network: their gradients arrive when backward ends, so
     nothing is left to hide its all-reduce behind) is kept small (``tail_mb``, default 8 MiB): the
     exposed tail of the communication is one sub-millisecond collective, not a 256 MiB one;
   * the FIRST bucket is small too (``head_mb``, default 64 MiB = 4 % of the 64x64 U-Net's 1.66 GB of gradients): the
     links start working within the first tenth of backward instead of after a full 256 MiB has accumulated;
-  * with more than one rank the wire format defaults to bf16 (``wire_dtype="auto"``): half the bytes per link, fp32
-    accumulation on arrival (pass ``torch.float32`` for an fp32 wire);
+  * the wire format follows the arithmetic of the step (``wire_dtype="auto"``): fp32 -- what the reference's DDP
+    reduces in -- unless the train step runs under bf16 autocast over RCCL (``note_autocast``, called by
+    ``train_batch``), where the gradients were computed from bf16 activations anyway and bf16 on the wire halves the
+    bytes per link.  The gradients are divided by the world size in fp32 BEFORE the cast; the cross-rank SUM itself then
+    runs in bf16 inside RCCL, the arena the optimizer reads is fp32.  Pass a dtype to pin either format;
   * ``record_timeline=True`` stamps every bucket's issue and completion with HIP events (``timeline()``), so the first
     run on a multi-GPU node shows how much of the exchange hid behind backward (``bench.py --gpus N`` prints it).
 
@@ -86,13 +93,15 @@ class GradReducer:
             self.nranks = int(world_override)
         # ``world`` > 1 switches the hooks / buckets / collectives on (a forced single-rank run pretends 2)
         self.world = self.nranks if not (force_collectives and self.nranks == 1 and dist.is_initialized()) else 2
+        self._wire_auto = False
         if isinstance(wire_dtype, str):
             if wire_dtype != "auto":
                 raise ValueError("wire_dtype: a torch dtype, None (fp32) or 'auto'")
-            # bf16 on the wire whenever there IS a wire (and the backend is a GPU one: gloo reduces bf16 slowly)
-            nccl = dist.is_initialized() and str(dist.get_backend(group)).lower() == "nccl"
-            wire_dtype = torch.bfloat16 if (self.nranks > 1 and nccl and self.params and self.params[0].is_cuda) else None
+            self._wire_auto = True      # fp32 until note_autocast(True) says the step computes in bf16
+            wire_dtype = None
         self.wire_dtype = wire_dtype
+        self._wire = {}                 # bucket -> persistent wire buffer (bf16 wire only)
+        self._comm = None               # communication stream (GPU tensors, world > 1)
         self.record_timeline = bool(record_timeline)
         self._timeline = []        # (bucket, bytes on the wire, issue event, done event) of the current step
         self._t0 = None
@@ -169,6 +178,22 @@ class GradReducer:
             return
         self._count(p)
 
+    def note_autocast(self, bf16: bool):
+        """``wire_dtype="auto"``: the step's compute dtype decides the wire format -- bf16 only for a bf16-autocast step on
+        GPU tensors over RCCL (gloo reduces bf16 slowly, and an fp32 step keeps the reference's fp32 reduction)."""
+        if not self._wire_auto or self._work:
+            return
+        nccl = dist.is_initialized() and str(dist.get_backend(self.group)).lower() == "nccl"
+        want = torch.bfloat16 if (bf16 and self.nranks > 1 and nccl and self.params and self.params[0].is_cuda) else None
+        if want != self.wire_dtype:
+            self.wire_dtype = want
+            self._wire = {}
+
+    def _comm_stream(self):
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=self.flat.device)
+        return self._comm
+
     # -- once per parameter per synchronised backward (from the hook, or from ready())
     def _count(self, p):
         if not self._enabled:
@@ -185,37 +210,53 @@ class GradReducer:
             self._streams[b].add(torch.cuda.current_stream())
         self._pending[b] -= 1
         if self._pending[b] == 0:
-            if p.is_cuda:
-                cur = torch.cuda.current_stream()
-                for st in self._streams[b]:
-                    if st != cur:
-                        cur.wait_stream(st)
-                self._streams[b] = set()
             self._launch(b)
 
     def _launch(self, b):
         s, e = self.buckets[b]
         buf = self.flat[s:e]
-        ev = None
-        if self.record_timeline and buf.is_cuda:
-            if self._t0 is None:   # first bucket of the step: the clock starts at the first issue
-                self._t0 = torch.cuda.Event(enable_timing=True)
-                self._t0.record()
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-        if self.wire_dtype is not None and self.wire_dtype != torch.float32:
-            wire = buf.to(self.wire_dtype)
-            wire.div_(self.nranks)
-            h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._work.append((h, buf, wire))
-            nbytes = wire.numel() * wire.element_size()
-        else:
+        if not buf.is_cuda:
             buf.div_(self.nranks)  # pre-scale: SUM of pre-divided == AVG, and gloo has no AVG
-            h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._work.append((h, None, None))
-            nbytes = buf.numel() * 4
-        if ev is not None:
-            self._timeline.append([b, nbytes, ev, None])
+            if self.wire_dtype is not None and self.wire_dtype != torch.float32:
+                wire = buf.to(self.wire_dtype)
+                h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._work.append((h, buf, wire, None))
+            else:
+                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._work.append((h, None, None, None))
+            return
+        # GPU: the communication stream waits for every producer of the bucket (an event at each producer stream's
+        # current tail: streams run in order, so that covers its last gradient of the bucket) -- no compute stream is
+        # made to wait -- and everything that touches the bucket from here to the copy-back runs on that stream
+        comm = self._comm_stream()
+        for st in self._streams[b]:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            comm.wait_event(ev)
+        self._streams[b] = set()
+        with torch.cuda.stream(comm):
+            ev0 = None
+            if self.record_timeline:
+                if self._t0 is None:   # first bucket of the step: the clock starts at the first issue
+                    self._t0 = torch.cuda.Event(enable_timing=True)
+                    self._t0.record(comm)
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record(comm)
+            buf.mul_(1.0 / self.nranks)   # in fp32, whatever goes on the wire
+            if self.wire_dtype is not None and self.wire_dtype != torch.float32:
+                wire = self._wire.get(b)
+                if wire is None:
+                    wire = self._wire[b] = torch.empty(e - s, dtype=self.wire_dtype, device=buf.device)
+                wire.copy_(buf)
+                h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._work.append((h, buf, wire, ev0))
+                nbytes = wire.numel() * wire.element_size()
+            else:
+                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._work.append((h, None, None, ev0))
+                nbytes = buf.numel() * 4
+            if ev0 is not None:
+                self._timeline.append([b, nbytes, ev0, None])
 
     def no_sync(self):
         """context manager for gradient-accumulation micro-steps (train_parallel.py:201-203)"""
@@ -251,14 +292,23 @@ class GradReducer:
                 lost = [(i, tuple(p.shape), self._fired.get(id(p), 0)) for i, p in enumerate(self.params) if self._fired.get(id(p), 0) != 1]
                 raise RuntimeError("buckets %s did not receive all their gradients; parameters (index, shape) that "
                                    "did not report exactly once (index, shape, count): %s" % (missing, lost[:12]))
-            for i, (h, buf, wire) in enumerate(self._work):
-                h.wait()
-                if wire is not None:
-                    buf.copy_(wire)
-                if self.record_timeline and i < len(self._timeline) and self._timeline[i][3] is None:
-                    done = torch.cuda.Event(enable_timing=True)
-                    done.record()   # on the compute stream, right behind its wait for this bucket's collective
-                    self._timeline[i][3] = done
+            comm = self._comm if (self._comm is not None and self.flat.is_cuda) else None
+            for i, (h, buf, wire, ev0) in enumerate(self._work):
+                if comm is None:
+                    h.wait()
+                    if wire is not None:
+                        buf.copy_(wire)
+                    continue
+                with torch.cuda.stream(comm):
+                    h.wait()                  # the communication stream waits for RCCL's
+                    if wire is not None:
+                        buf.copy_(wire)
+                    if self.record_timeline and i < len(self._timeline) and self._timeline[i][3] is None:
+                        done = torch.cuda.Event(enable_timing=True)
+                        done.record(comm)     # right behind the collective (and the copy-back of a bf16 wire)
+                        self._timeline[i][3] = done
+            if comm is not None:
+                torch.cuda.current_stream().wait_stream(comm)   # the ONE wait of a compute stream: before the optimizer
             self._work = []
             if self.record_timeline:
                 self._last_timeline, self._last_t0 = self._timeline, self._t0
@@ -267,9 +317,27 @@ class GradReducer:
             self._fired = {}
         self._deferred = set()
 
+    def mark(self, what):
+        """``record_timeline``: stamp the start ("bw0", before ``loss.backward()``) / the end ("bw1", behind everything
+        backward queued on the compute stream, before the join with the communication stream) of a backward pass on
+        the current stream, so the bucket times can be read against the window they are meant to hide in"""
+        if self.record_timeline and self.flat.is_cuda and self.world > 1:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            setattr(self, "_" + what, ev)
+
+    def backward_window_ms(self):
+        """(first bucket issue, end of backward) in ms after the start of backward, of the last finished step"""
+        b0, b1, t0 = getattr(self, "_bw0", None), getattr(self, "_bw1", None), getattr(self, "_last_t0", None)
+        if b0 is None or b1 is None or t0 is None:
+            return None
+        torch.cuda.synchronize()
+        return b0.elapsed_time(t0), b0.elapsed_time(b1)
+
     def timeline(self):
-        """[(bucket, wire bytes, issue ms, done ms)] of the last finished step, relative to its first issue; ``done`` is
-        when the compute stream could proceed past the bucket (record_timeline=True; synchronises the device)"""
+        """[(bucket, wire bytes, issue ms, done ms)] of the last finished step, relative to its first issue, both on the
+        communication stream: ``issue`` = every producer of the bucket has finished, ``done`` = the averaged gradients
+        are back in the arena (record_timeline=True; synchronises the device)"""
         tl, t0 = getattr(self, "_last_timeline", None), getattr(self, "_last_t0", None)
         if not tl or t0 is None:
             return []

@@ -492,7 +492,10 @@ def profile_begin(shapes: bool = False):
     _prof, _prof_shapes = [], shapes
 
 
-def _prof_wrap(name, work, fn, kind="mfma"):
+def _prof_wrap(name, work, fn, kind="mfma", executed=None):
+    """``work``: algorithmic FLOPs (bytes for kind="hbm") the launch is credited with; ``executed``: the FLOPs it actually
+    issues when that differs (the sub-pixel resampling convolutions are credited with the dense 3x3 count of the layer
+    they replace and execute 16 / 36 of it)"""
     if _prof is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -503,7 +506,7 @@ def _prof_wrap(name, work, fn, kind="mfma"):
         real = _lib.lib().mdm_last_gemm_kernel()   # the kernel that actually ran (name as rocprofv3 prints it)
         if real:
             name = real.decode() + (name[name.index(" M="):] if " M=" in name else "")
-    _prof.append((kind, name, work, e0, e1))
+    _prof.append((kind, name, work, e0, e1, work if executed is None else executed))
     return r
 
 
@@ -515,15 +518,22 @@ def profile_end(peak_tflops, peak_gbs=8000.0):
     rec, _prof = _prof, None
     torch.cuda.synchronize()
     agg, hbm = {}, {}
-    for kind, name, work, e0, e1 in rec:
-        a = (hbm if kind == "hbm" else agg).setdefault(name, [0, 0.0, 0.0])
+    for kind, name, work, e0, e1, executed in rec:
+        a = (hbm if kind == "hbm" else agg).setdefault(name, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += work
         a[2] += e0.elapsed_time(e1) * 1e-3
+        a[3] += executed
     if not agg:
         return None
     table = {k: {"launches": v[0], "alg_tflop": round(v[1] / 1e12, 3), "time_ms": round(v[2] * 1e3, 3),
                  "tflops": round(v[1] / v[2] / 1e12, 1)} for k, v in agg.items()}
+    for k, v in agg.items():
+        if abs(v[3] - v[1]) > 1e-6 * v[1]:
+            # credited with more FLOPs than it issues: "tflops" is algorithmic credit (it may exceed the MFMA peak),
+            # "executed_tflops" is what the matrix pipe does
+            table[k]["executed_tflops"] = round(v[3] / v[2] / 1e12, 1)
+            table[k]["tflops_is"] = "credit for the dense 3x3 layer this sub-pixel kernel replaces (%.2fx the FLOPs it executes)" % (v[1] / v[3])
     dom = max(agg, key=lambda k: agg[k][2])
     n, fl, t = agg[dom]
     ach = fl / t / 1e12
@@ -683,7 +693,8 @@ def _conv_backward(ctx, x, weight, bias, dy):
             wsel = packed_s2_dgrad_weight(weight)
             _prof_wrap("conv_gemm_bl_kernel<sel4> (3x3 stride-2 input gradient) M=%d N=%d K=%d" % (N * Ho * Wo, 4 * cin, 4 * cout),
                        2.0 * N * Ho * Wo * cout * 9 * cin, lambda: _lib.check(
-                _lib.lib().mdm_conv_s2_dgrad(_p(dy), _p(wsel), _p(dx), N, Ho, Wo, cout, cin, BF16, _stream()), "mdm_conv_s2_dgrad"))
+                _lib.lib().mdm_conv_s2_dgrad(_p(dy), _p(wsel), _p(dx), N, Ho, Wo, cout, cin, BF16, _stream()), "mdm_conv_s2_dgrad"),
+                       executed=2.0 * N * Ho * Wo * (4 * cin) * (4 * cout))
         elif ks == 3 and stride == 2:
             _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, 3, 1, 1, 0, kbd)
         else:
@@ -833,7 +844,8 @@ class UpsampleConvFn(torch.autograd.Function):
         y = torch.empty((N, 2 * H, 2 * W, cout), dtype=x.dtype, device=x.device)
         _prof_wrap("conv_gemm_bl_kernel<sel4> (upsample2x + 3x3) M=%d N=%d K=%d" % (N * H * W, 4 * cout, 4 * cin),
                    2.0 * N * 4 * H * W * cout * 9 * cin, lambda: _lib.check(
-            _lib.lib().mdm_conv_up_fwd(_p(x), _p(w_ph), _p(bias4), _p(y), N, H, W, cin, cout, BF16, _stream()), "mdm_conv_up_fwd"))
+            _lib.lib().mdm_conv_up_fwd(_p(x), _p(w_ph), _p(bias4), _p(y), N, H, W, cin, cout, BF16, _stream()), "mdm_conv_up_fwd"),
+                   executed=2.0 * N * H * W * (4 * cout) * (4 * cin))
         ctx.save_for_backward(x, weight, bias)
         return y
 
@@ -852,7 +864,8 @@ class UpsampleConvFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             _prof_wrap("conv_gemm_bl_kernel<sel4> (upsample2x + 3x3 input gradient) M=%d N=%d K=%d" % (N * H * W, cin, 16 * cout),
                        2.0 * N * 4 * H * W * cout * 9 * cin, lambda: _lib.check(
-                L.mdm_conv_up_dgrad(_p(dyb), _p(w_t), _p(dx), N, H, W, cout, cin, BF16, _stream()), "mdm_conv_up_dgrad"))
+                L.mdm_conv_up_dgrad(_p(dyb), _p(w_t), _p(dx), N, H, W, cout, cin, BF16, _stream()), "mdm_conv_up_dgrad"),
+                           executed=2.0 * N * H * W * cin * (16 * cout))
         if ctx.needs_input_grad[1]:
             want_b = bias is not None and ctx.needs_input_grad[2]
             slot = _slot(weight)
@@ -869,7 +882,7 @@ class UpsampleConvFn(torch.autograd.Function):
                 _prof_wrap("conv_wgrad_bl_kernel<1, 1> (upsample2x + 3x3, 16 of 36 blocks) M=%d N=%d K=%d" % (M, 4 * cout, K),
                            2.0 * 4 * M * cout * K, lambda: _lib.check(
                     L.mdm_conv_wgrad_blocked(_p(x), _p(dyb), 1 if want_b else 0, _p(ws), N, H, W, cin, cout, BF16, _stream()),
-                    "mdm_conv_wgrad_blocked"))
+                    "mdm_conv_wgrad_blocked"), executed=2.0 * 4 * M * cout * K * 16.0 / 36.0)
                 _lib.check(L.mdm_conv_wgrad_reduce(_p(ws), _p(dwb), _p(db4), _p(dyb), M, cin, 4 * cout, 3, 0, BF16, _stream()),
                            "mdm_conv_wgrad_reduce")
                 dwo = slot if sunk else torch.empty(weight.shape, dtype=torch.float32, device=x.device)

@@ -78,6 +78,7 @@ class FusedState:
     def finish_backward(self):
         """everything that has to be in the gradient arena before the optimizer reads it"""
         ops.flush_wgrad_queue()
+        self.reducer.mark("bw1")
         ops.join_side_stream()
         self.reducer.finish()
 
@@ -310,6 +311,7 @@ def _train_batch_fused(st, model, sample, optimizer, scheduler, logger, args, ac
     lockstep = st.reducer.world > 1 and not accumulate_gradient
     if ops._grad_sink is not st.reducer:
         st.activate()   # another FusedState (a second model in the same process) was used in between
+    st.reducer.note_autocast(fp16)   # wire_dtype="auto": bf16 on the wire only for a bf16 step over RCCL
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=fp16):
         losses, times, x_t, means, targets, weights = model.get_loss(sample)
         loss = _loss_of(losses, weights)
@@ -324,6 +326,7 @@ def _train_batch_fused(st, model, sample, optimizer, scheduler, logger, args, ac
                 return _fused_nan_return(st, optimizer, scheduler, fp16, loss_val, losses, times, x_t, means, targets, True)
         if fp16 and num_grad_accumulations != 1:
             loss = loss / num_grad_accumulations
+    st.reducer.mark("bw0")
     loss.backward()   # (fp32: the reference divides by num_grad_accumulations only AFTER this, trainer.py:73-75: no effect)
     # also after an accumulation micro-step: nothing queued (grouped weight gradients, GroupNorm parameter rows) may cross
     # into the next micro-step, where its ready() report would release a bucket before that step's own gradient is
@@ -471,6 +474,7 @@ class TrainStep:
             # same outcome as the reference's early return (trainer.py:38-41), identical on every rank without a
             # collective.  The value itself travels to pinned host memory behind the forward and is read once backward
             # and the optimizer tail are queued: the host never waits for the GPU in the middle of a step.
+            self.state.reducer.note_autocast(self.bf16)
             self.state.post_scalar("loss", loss)
             loss.backward()
             self.state.finish_backward()

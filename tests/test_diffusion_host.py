@@ -168,3 +168,93 @@ def test_registry_install_replaces_reference_models():
         assert pipe.get_model().vision_model.model_type == "unet"
     finally:
         R.config.MODEL_REGISTRY.update(prev)
+
+
+def _oracle_forward(self, x_t, times, conditioning=None, cond_mask=None, micros=None):
+    """stand-in for the HIP forward of mdm_hip.UNet / NestedUNet in the conformance test below: the oracle's restatement of
+    the same function on the module's own parameters (TEST ONLY -- the product's ops raise on CPU tensors)"""
+    sd = dict(self.named_parameters())   # (not state_dict(): that detaches)
+    return O.model_forward(sd, self.config, x_t, times, conditioning, cond_mask, micros or {})
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("case", ["mini_unet", "mini_nested"])
+def test_reference_pipeline_drives_the_hip_modules_call_surface(case, tmp_path, monkeypatch):
+    """The REAL ``ml_mdm.diffusion.Diffusion`` / ``NestedDiffusion`` (reference diffusion.py:91-98, 295-313) wrapped around
+    this package's ``UNet`` / ``NestedUNet`` -- the objects clis/train_parallel.py:66-72 builds once the registry is swapped
+    -- run end to end on CPU: ``get_loss`` (noising, micro-conditioning dict, list inputs of the nested model, loss
+    weights), ``sample`` (the sampler's calls into the vision model: tensor vs list conventions, ``nest_ratio``,
+    ``is_temporal``, ``conditions``), ``save`` / ``load`` through the pipeline's ``Model`` (diffusion.py:66-70).  Only the arithmetic INSIDE the module's
+    forward is replaced -- by the oracle, in this test -- so every attribute, argument and return convention the reference
+    pipeline relies on is the product's; the same pipeline around the reference's own module with the same weights must
+    give the same numbers."""
+    import make_golden as MG
+    import mdm_hip
+    import parity_cases as PC
+    import ref_import
+
+    R = ref_import.load()
+    monkeypatch.setattr(mdm_hip.UNet, "forward", _oracle_forward)
+    monkeypatch.setattr(mdm_hip.NestedUNet, "forward", _oracle_forward)
+    ours, cfg, sd = PC.build_module(case)
+    nested = hasattr(cfg, "inner_config")
+    ref_cls = R.nested_unet.NestedUNet if nested else R.unet.UNet
+    theirs = ref_cls(3, 3, MG.to_ref_cfg(R, cfg))
+    theirs.load_state_dict(sd)
+    RS = R.samplers
+    scfg = RS.SamplerConfig(num_diffusion_steps=1000, schedule_type=RS.ScheduleType.DEEPFLOYD,
+                            prediction_type=RS.PredictionType.V_PREDICTION, loss_target_type=RS.PredictionType.DDPM,
+                            threshold_function=RS.ThresholdType.CLIP)
+    if nested:
+        dcfg = R.diffusion.NestedDiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False, use_double_loss=True,
+                                                 no_use_residual=True, multi_res_weights="4:1")
+        P = R.diffusion.NestedDiffusion
+    else:
+        dcfg = R.diffusion.DiffusionConfig(sampler_config=scfg, use_vdm_loss_weights=False)
+        P = R.diffusion.Diffusion
+    pipe_o, pipe_r = P(ours, dcfg), P(theirs, dcfg)
+    assert pipe_o.get_model().vision_model is ours and pipe_o.get_model().input_channels == 3
+
+    side = PC._SIDES[case][0]
+    g = torch.Generator().manual_seed(11)
+    sample = {"images": torch.rand(2, 3, side, side, generator=g) * 2 - 1, "lm_outputs": torch.randn(2, 8, 64, generator=g),
+              "lm_mask": torch.ones(2, 8), "scale": torch.tensor([0.3, 1.7])}
+    sample["lm_mask"][1, 5:] = 0
+    outs = []
+    for pipe in (pipe_o, pipe_r):
+        pipe.train()
+        torch.manual_seed(23)
+        outs.append(pipe.get_loss(sample))
+    for a, b in zip(outs[0], outs[1]):
+        if a is None or b is None:
+            assert a is None and b is None
+            continue
+        for u, v in zip(a if isinstance(a, (list, tuple)) else [a], b if isinstance(b, (list, tuple)) else [b]):
+            assert u.shape == v.shape and O.rel_l2(u.float(), v.float()) < 1e-4
+    # the loss is differentiable w.r.t. the product module's parameters through the real pipeline
+    outs[0][0].mean().backward()
+    assert all(p.grad is not None for p in ours.parameters())
+
+    # classifier-free guidance: the caller hands over [unconditional | conditional] text states (clis/generate_sample.py:230-256)
+    cfg_sample = dict(sample, lm_outputs=torch.cat([torch.zeros_like(sample["lm_outputs"]), sample["lm_outputs"]]),
+                      lm_mask=torch.cat([sample["lm_mask"]] * 2), scale=torch.cat([sample["scale"]] * 2))
+    imgs = []
+    for pipe in (pipe_o, pipe_r):
+        pipe.eval()
+        torch.manual_seed(29)
+        with torch.no_grad():
+            imgs.append(pipe.sample(2, cfg_sample, side, torch.device("cpu"), resample_steps=True, num_inference_steps=3,
+                                    guidance_scale=1.5))
+    assert imgs[0].shape == imgs[1].shape and O.rel_l2(imgs[0], imgs[1]) < 1e-4
+
+    # checkpoint through the pipeline (diffusion.py:66-70): written by the product module, read by the reference's and back
+    f = str(tmp_path / "vis.pth")
+    pipe_o.get_model().save(f, other_items={"step": 3})
+    theirs2 = ref_cls(3, 3, MG.to_ref_cfg(R, cfg))
+    P(theirs2, dcfg).get_model().load(f)
+    for (k, a), (_, b) in zip(sorted(ours.state_dict().items()), sorted(theirs2.state_dict().items())):
+        assert torch.equal(a, b), k
+    pipe_r.get_model().save(f)
+    ours2, _, _ = PC.build_module(case, seed=5)
+    P(ours2, dcfg).get_model().load(f)
+    assert all(torch.equal(a, b) for a, b in zip(ours2.state_dict().values(), theirs.state_dict().values()))
