@@ -339,8 +339,17 @@ def main():
             # The reference's sampling path has no autocast (diffusion.py:181-197, clis/generate_sample.py:230-256): the
             # same iterations on fp32 tensors, (a) products as three bf16 MFMAs (MDM_F32_SPLIT -- passes the 1e-3 gate on
             # the long-horizon goldens, tests/test_model_gpu.py) and (b) the exact-fp32 MFMA path, for scale.
-            def fp32_leg(split, iters):
+            def fp32_leg(split, iters, graphed=False):
                 with torch.no_grad(), ops.fp32_split(split):
+                    if graphed:   # the product's sampling path, in this arithmetic (the graph is keyed on it)
+                        from mdm_hip.graph import GraphedSampler
+                        g = GraphedSampler(pipe, warmup=1)
+                        g.sample(sb, ssample, side, device, num_inference_steps=iters, ddim_eta=0)   # builds the graph
+                        sync()
+                        t0_ = time.perf_counter()
+                        g.sample(sb, ssample, side, device, num_inference_steps=iters, ddim_eta=0)
+                        sync()
+                        return (time.perf_counter() - t0_) / iters * 1e3
                     pipe.sample(sb, ssample, side, device, resample_steps=True, num_inference_steps=1, ddim_eta=0)
                     sync()
                     t0_ = time.perf_counter()
@@ -348,11 +357,18 @@ def main():
                     sync()
                     return (time.perf_counter() - t0_) / iters * 1e3
             try:
-                ms_x3 = fp32_leg(True, 4)
-                samp["fp32_bf16x3"] = {"ms_per_denoise_step": round(ms_x3, 3), "ratio_to_bf16_eager": round(ms_x3 / ms_eager, 2),
+                ms_x3e = fp32_leg(True, 4)
+                ms_x3, how3 = ms_x3e, "eager"
+                if world == 1:
+                    try:
+                        ms_x3, how3 = fp32_leg(True, 4, graphed=True), "one hipGraph replay per iteration (GraphedSampler)"
+                    except Exception as ex:
+                        how3 = "eager (graph capture failed: %s)" % str(ex)[:80]
+                samp["fp32_bf16x3"] = {"ms_per_denoise_step": round(ms_x3, 3), "ms_per_denoise_step_eager": round(ms_x3e, 3),
+                                       "ratio_to_bf16": round(ms_x3 / ms_it, 2), "ratio_to_bf16_eager": round(ms_x3e / ms_eager, 2),
                                        "images_per_s_at_%d_steps" % demo_steps: round(world * sb / (demo_steps * ms_x3 / 1e3), 3),
                                        "arithmetic": "fp32 tensors / accumulators, products as 3 bf16 MFMAs on hi + lo halves; 1e-3 gate: pass",
-                                       "sampler": "eager", "timed_steps": 4}
+                                       "sampler": how3, "timed_steps": 4}
                 ms_ex = fp32_leg(False, 2)
                 samp["fp32_exact"] = {"ms_per_denoise_step": round(ms_ex, 3), "ratio_to_bf16_eager": round(ms_ex / ms_eager, 2),
                                       "arithmetic": "v_mfma_f32_16x16x4_f32 (1/16 of the bf16 MFMA rate)", "sampler": "eager", "timed_steps": 2}
@@ -468,9 +484,22 @@ def main():
                     ts = time.perf_counter()
                     p4.sample(4, s4, 1024, device, resample_steps=True, num_inference_steps=3, ddim_eta=1)
                     sync()
-                    ms4x = (time.perf_counter() - ts) / 3 * 1e3
-                n1024["fp32_bf16x3"] = {"ms_per_denoise_step": round(ms4x, 3), "ratio_to_bf16": round(ms4x / ms4, 2),
-                                        "seconds_per_250_steps": round(ms4x * 250 / 1e3, 3), "sampler": "eager", "timed_steps": 3}
+                    ms4e = (time.perf_counter() - ts) / 3 * 1e3
+                    ms4x, how4 = ms4e, "eager"
+                    try:
+                        g4 = GraphedSampler(p4, warmup=1)
+                        g4.sample(4, s4, 1024, device, num_inference_steps=3, ddim_eta=1)   # builds the graph
+                        sync()
+                        ts = time.perf_counter()
+                        g4.sample(4, s4, 1024, device, num_inference_steps=3, ddim_eta=1)
+                        sync()
+                        ms4x, how4 = (time.perf_counter() - ts) / 3 * 1e3, "one hipGraph replay per iteration (GraphedSampler)"
+                        del g4
+                    except Exception as ex:
+                        how4 = "eager (graph capture failed: %s)" % str(ex)[:80]
+                n1024["fp32_bf16x3"] = {"ms_per_denoise_step": round(ms4x, 3), "ms_per_denoise_step_eager": round(ms4e, 3),
+                                        "ratio_to_bf16": round(ms4x / ms4, 2), "seconds_per_250_steps": round(ms4x * 250 / 1e3, 3),
+                                        "sampler": how4, "timed_steps": 3}
             except Exception as ex:
                 n1024["fp32_bf16x3"] = {"error": str(ex)[:200]}
             del p4, net

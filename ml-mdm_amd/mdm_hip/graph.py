@@ -227,6 +227,7 @@ class GraphedSampler:
                   for k, v in self.pipe.get_micro_conditioning(sample).items()}
         key = (tuple(tuple(x.shape) for x in xs), tuple(cond.shape), int(num_inference_steps), ddim_eta, float(guidance_scale),
                torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else None,
+               ops.fp32_split_enabled(),   # a captured graph keeps the arithmetic it was captured with
                tuple(sorted((k, tuple(v.shape)) for k, v in micros.items())))
         ent = self._graphs.get(key) or self._build(key, xs, cond, mask, int(num_inference_steps), ddim_eta, float(guidance_scale), micros)
         for sx, x in zip(ent["x"], xs):

@@ -25,8 +25,12 @@ _fp32_split = False
 
 
 class fp32_split:
-    """``with ops.fp32_split():`` (or ``ops.fp32_split(True)`` / ``(False)`` as a switch) -- fp32 forward passes inside run
-    their convolutions, linears and attention as bf16x3 products.  No effect on bf16 tensors or on backward kernels."""
+    """``with ops.fp32_split():`` (or ``ops.fp32_split(True)`` / ``(False)`` as a switch) -- every matmul-class launch on
+    fp32 tensors inside (convolutions, linears, the attention forward; ALSO the input-gradient GEMMs of a backward pass run
+    inside the context: they share the forward kernels) forms its products as bf16x3.  No effect on bf16 tensors, on the
+    weight-gradient and attention-backward kernels.  It is a sampling mode: a process-wide switch (not thread-safe), read at
+    launch time -- a hipGraph captured by ``GraphedSampler`` keeps the arithmetic it was captured with, and the sampler
+    keys its graphs on the switch."""
 
     def __init__(self, enabled: bool = True):
         global _fp32_split
@@ -39,6 +43,10 @@ class fp32_split:
     def __exit__(self, *a):
         global _fp32_split
         _fp32_split = self._prev
+
+
+def fp32_split_enabled() -> bool:
+    return _fp32_split
 
 
 def _dt_mm(t: torch.Tensor) -> int:
@@ -139,9 +147,12 @@ def enable_async_wgrad(flag: bool):
 
 
 def side_stream():
+    """the weight-gradient stream.  MDM_HIP_SIDE_PRIO (development A/B): its HIP stream priority (-1 high, 0 the default
+    streams', 1 low where the runtime has a third level)"""
     global _side_stream
     if _side_stream is None:
-        _side_stream = torch.cuda.Stream()
+        prio = int(os.environ.get("MDM_HIP_SIDE_PRIO", "0"))
+        _side_stream = torch.cuda.Stream(priority=prio) if prio else torch.cuda.Stream()
     return _side_stream
 
 

@@ -41,13 +41,15 @@ class FusedState:
     def __init__(self, net, reducer=None, bucket_mb=256.0, wire_dtype="auto", use_ema=True, async_wgrad=True):
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
-        self.reducer = reducer if reducer is not None else GradReducer(self.params, bucket_mb=bucket_mb, wire_dtype=wire_dtype)
+        late = net.late_gradient_parameters() if hasattr(net, "late_gradient_parameters") else None
+        self.reducer = reducer if reducer is not None else GradReducer(self.params, bucket_mb=bucket_mb, wire_dtype=wire_dtype,
+                                                                       late_params=late)
         self.reducer.broadcast_parameters(0)
         flat = torch.empty_like(self.reducer.flat)
         self.slices = {}
         off = 0
         with torch.no_grad():
-            for p in reversed(self.params):
+            for p in self.reducer.order:    # the arenas share the gradient arena's layout: the optimizer walks them in step
                 n = p.numel()
                 flat[off:off + n].copy_(p.reshape(-1))
                 p.data = flat[off:off + n].view_as(p)
@@ -166,6 +168,8 @@ def _adopt(model, optimizer, ema_model):
             return no("ModelEma on another device / of another shape / with persistent buffers")
     reducer = wrapped.reducer if isinstance(wrapped, DataParallel) else \
         GradReducer(params, group=None, world_override=1)   # an unwrapped model trains locally, whatever torch.distributed holds
+    if [id(p) for p in reducer.params] != [id(p) for p in params]:
+        return no("the DataParallel wrapper's reducer does not hold exactly the vision model's parameters")
     had_state = {id(p): dict(optimizer.state.get(p, {})) for p in params}
     # MDM_HIP_SERIAL_WGRAD=1 (profiling aid, bench.py --serial-wgrad): weight gradients on the main stream
     st = FusedState(net, reducer=reducer, use_ema=ema_net is not None, async_wgrad=os.environ.get("MDM_HIP_SERIAL_WGRAD", "0") != "1")

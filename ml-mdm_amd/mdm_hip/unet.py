@@ -544,6 +544,18 @@ class UNet(nn.Module):
         kv = ops.text_kv(cond, quads, layers[0].norm_cond.eps)
         return TextStates(cond, {id(m): t for m, t in zip(layers, kv)})
 
+    def late_gradient_parameters(self):
+        """parameters whose gradients are complete only when backward ENDS although they are registered inside the
+        blocks: the layers evaluated for the whole network in one grouped launch at the start of forward (time_states,
+        text_states).  A gradient reducer puts them at the end of its arena (mdm_hip.distributed.GradReducer)."""
+        out = []
+        for m in self.modules():
+            if isinstance(m, ResNet):
+                out += list(m.time_layer.parameters())
+            elif isinstance(m, SelfAttention) and m.cond_dim is not None and m.cond_dim > 0:
+                out += list(m.norm_cond.parameters()) + list(m.kv_cond.parameters())
+        return out
+
     def forward_micro_conditioning(self, times, micros):
         temb = None
         for key, default in self.conditions.items():

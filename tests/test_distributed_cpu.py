@@ -295,3 +295,32 @@ def test_train_batch_refuses_data_parallel_on_the_plain_path():
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 1.0)
     with pytest.raises(RuntimeError, match="only works with the fused train step"):
         trainer.train_batch(model, {}, opt, sched, None, types.SimpleNamespace(fp16=False))
+
+
+def test_late_gradient_parameters_go_to_the_end_of_the_arena():
+    """the layers a UNet evaluates for the whole network in one grouped launch at the start of forward (every ResNet's
+    time_layer, every attention layer's norm_cond / kv_cond) get their gradients when backward ENDS: the reducer puts
+    them behind everything else, so that no earlier bucket waits for them (mdm_hip.distributed.GradReducer late_params)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "ml-mdm_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import parity_cases as PC
+    from mdm_hip import distributed as md
+
+    model, _, _ = PC.build_module("mini_unet")
+    late = model.late_gradient_parameters()
+    names = {id(p): n for n, p in model.named_parameters()}
+    assert late and all(("time_layer" in names[id(p)]) or ("norm_cond" in names[id(p)]) or ("kv_cond" in names[id(p)]) for p in late)
+    n_late = sum(p.numel() for p in late)
+    red = md.GradReducer(list(model.parameters()), bucket_mb=0.05, head_mb=0.01, tail_mb=0.002, late_params=late, world_override=1)
+    total = red.flat.numel()
+    late_ids = {id(p) for p in late}
+    base = red.flat.data_ptr()
+    for p in model.parameters():
+        off = (p.grad.data_ptr() - base) // 4
+        assert (off >= total - n_late) == (id(p) in late_ids), names[id(p)]
+    # the others keep the order backward produces them in (reverse registration)
+    early = [p for p in red.order if id(p) not in late_ids]
+    assert [id(p) for p in early] == [id(p) for p in reversed(list(model.parameters())) if id(p) not in late_ids]
+    assert [id(p) for p in red.order[len(early):]] == [id(p) for p in reversed(list(model.parameters())) if id(p) in late_ids]
