@@ -1263,7 +1263,7 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
 // drives the experiment -- no environment lookups inside the boundary's entry points
 static int g_attn_bwd_mode = 0;
 extern "C" int mdm_dev_set_attn_bwd(int mode) {
-  if (mode < 0 || mode > 4) return -1;
+  if (mode < 0 || mode > 5) return -1;
   g_attn_bwd_mode = mode;
   return 0;
 }
@@ -1312,6 +1312,7 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
     if constexpr (D == 64) {
       // long sequences (the 32x32 level: L = 1024, d = 64): the same tile steps, keys / queries streamed through LDS
       // (d = 96 would spill: 256 registers hold the accumulators and operands of a step, not the stream's staging on top)
+      // (5 = "auto, but long sequences on the 16x16x32 streaming kernels": A/B of the in-step effect)
       if (((a.L > 256 && g_attn_bwd_mode == 0) || g_attn_bwd_mode == 4) && (!a.kc || a.S <= 32)) {
         constexpr int smem_dq = attn_bwd_dq32_lds<D>(), smem_dkv = attn_bwd_dkv32_lds<D>();
         ensure_dynamic_lds(attn_bwd_dq32_kernel<D>, smem_dq);

@@ -168,7 +168,7 @@ def _apply_dev_env(handle):
     include/mdm_hip_dev.h -- the C entry points themselves never look at the environment."""
     mode = os.environ.get("MDM_HIP_ATTN_BWD")
     if mode:
-        handle.mdm_dev_set_attn_bwd({"split": 1, "small": 2, "small16": 3, "stream32": 4}.get(mode, 0))
+        handle.mdm_dev_set_attn_bwd({"split": 1, "small": 2, "small16": 3, "stream32": 4, "long16": 5}.get(mode, 0))
     if os.environ.get("MDM_HIP_SPLIT_FILL"):
         handle.mdm_dev_set_knob(6, int(os.environ["MDM_HIP_SPLIT_FILL"]))
     if os.environ.get("MDM_HIP_CONV_DIRECT") == "0":

@@ -204,6 +204,11 @@ class GradReducer:
             self._comm = torch.cuda.Stream(device=self.flat.device)
         return self._comm
 
+    def _post_stream(self):
+        if getattr(self, "_post", None) is None:
+            self._post = torch.cuda.Stream(device=self.flat.device)
+        return self._post
+
     # -- once per parameter per synchronised backward (from the hook, or from ready())
     def _count(self, p):
         if not self._enabled:
@@ -244,6 +249,7 @@ class GradReducer:
             ev.record(st)
             comm.wait_event(ev)
         self._streams[b] = set()
+        post = self._post_stream()
         with torch.cuda.stream(comm):
             ev0 = None
             if self.record_timeline:
@@ -252,21 +258,37 @@ class GradReducer:
                     self._t0.record(comm)
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev0.record(comm)
-            buf.mul_(1.0 / self.nranks)   # in fp32, whatever goes on the wire
+            scale = 1.0 / self.nranks   # applied in fp32, whatever goes on the wire
             if self.wire_dtype is not None and self.wire_dtype != torch.float32:
                 wire = self._wire.get(b)
                 if wire is None:
                     wire = self._wire[b] = torch.empty(e - s, dtype=self.wire_dtype, device=buf.device)
-                wire.copy_(buf)
+                # ONE pass: fp32 gradient x 1/n -> wire format (4 bytes read + 2 written per element, nothing in place)
+                if self.nranks > 1:
+                    torch.mul(buf, scale, out=wire)
+                else:
+                    wire.copy_(buf)
                 h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._work.append((h, buf, wire, ev0))
                 nbytes = wire.numel() * wire.element_size()
             else:
+                wire = None
+                if self.nranks > 1:
+                    buf.mul_(scale)
                 h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._work.append((h, None, None, ev0))
                 nbytes = buf.numel() * 4
+        # the completion side runs on its own stream, bucket by bucket in issue order: it waits for RCCL (this does not
+        # block the host), copies a bf16 wire back into the fp32 arena and stamps the bucket done -- while the
+        # communication stream is already preparing the next bucket
+        with torch.cuda.stream(post):
+            h.wait()
+            if wire is not None:
+                buf.copy_(wire)
+            done = None
             if ev0 is not None:
-                self._timeline.append([b, nbytes, ev0, None])
+                done = torch.cuda.Event(enable_timing=True)
+                done.record(post)
+                self._timeline.append([b, nbytes, ev0, done])
+        self._work.append((h, None, None, ev0))
 
     def no_sync(self):
         """context manager for gradient-accumulation micro-steps (train_parallel.py:201-203)"""
@@ -302,23 +324,15 @@ class GradReducer:
                 lost = [(i, tuple(p.shape), self._fired.get(id(p), 0)) for i, p in enumerate(self.params) if self._fired.get(id(p), 0) != 1]
                 raise RuntimeError("buckets %s did not receive all their gradients; parameters (index, shape) that "
                                    "did not report exactly once (index, shape, count): %s" % (missing, lost[:12]))
-            comm = self._comm if (self._comm is not None and self.flat.is_cuda) else None
-            for i, (h, buf, wire, ev0) in enumerate(self._work):
-                if comm is None:
+            if self._comm is not None and self.flat.is_cuda:
+                # GPU: every bucket's wait + copy-back is already queued on the completion stream; the optimizer's stream
+                # waits for that stream ONCE -- the only wait a compute stream does for the reducer
+                torch.cuda.current_stream().wait_stream(self._post_stream())
+            else:
+                for h, buf, wire, _ in self._work:
                     h.wait()
                     if wire is not None:
                         buf.copy_(wire)
-                    continue
-                with torch.cuda.stream(comm):
-                    h.wait()                  # the communication stream waits for RCCL's
-                    if wire is not None:
-                        buf.copy_(wire)
-                    if self.record_timeline and i < len(self._timeline) and self._timeline[i][3] is None:
-                        done = torch.cuda.Event(enable_timing=True)
-                        done.record(comm)     # right behind the collective (and the copy-back of a bf16 wire)
-                        self._timeline[i][3] = done
-            if comm is not None:
-                torch.cuda.current_stream().wait_stream(comm)   # the ONE wait of a compute stream: before the optimizer
             self._work = []
             if self.record_timeline:
                 self._last_timeline, self._last_t0 = self._timeline, self._t0
@@ -346,8 +360,8 @@ class GradReducer:
 
     def timeline(self):
         """[(bucket, wire bytes, issue ms, done ms)] of the last finished step, relative to its first issue, both on the
-        communication stream: ``issue`` = every producer of the bucket has finished, ``done`` = the averaged gradients
-        are back in the arena (record_timeline=True; synchronises the device)"""
+        communication / completion streams: ``issue`` = every producer of the bucket has finished, ``done`` = the averaged
+        gradients are back in the arena (record_timeline=True; synchronises the device)"""
         tl, t0 = getattr(self, "_last_timeline", None), getattr(self, "_last_t0", None)
         if not tl or t0 is None:
             return []

@@ -191,7 +191,7 @@ def _adopt(model, optimizer, ema_model):
         step_host = torch.tensor(float(steps))
         for p in params:
             optimizer.state[p]["step"] = step_host
-        optimizer.register_state_dict_pre_hook(lambda opt, st=st, t=step_host: t.fill_(float(int(st.step_dev))))
+        optimizer.register_state_dict_pre_hook(lambda opt, st=st, t=step_host: (_settle(st), t.fill_(float(int(st.step_dev)))) and None)
 
         def _reinstall(opt, st=st, params=params, t=step_host):
             # optimizer.load_state_dict() replaced the state entries with fresh tensors: copy them into the arenas the
@@ -313,6 +313,7 @@ def _train_batch_fused(st, model, sample, optimizer, scheduler, logger, args, ac
     # every rank runs backward and the common tail; the update is skipped on the device by all of them (the REDUCED
     # gradient norm is not finite), and all of them learn it from that norm, so scheduler / EMA counter stay identical
     lockstep = st.reducer.world > 1 and not accumulate_gradient
+    _settle(st)   # (a skipped previous step of a multi-rank run: see below)
     if ops._grad_sink is not st.reducer:
         st.activate()   # another FusedState (a second model in the same process) was used in between
     st.reducer.note_autocast(fp16)   # wire_dtype="auto": bf16 on the wire only for a bf16 step over RCCL
@@ -348,11 +349,7 @@ def _train_batch_fused(st, model, sample, optimizer, scheduler, logger, args, ac
             st.post_scalar("gnorm_sq", st.gnorm_sq)
     if loss_val is None:
         loss_val = st.read_scalar("loss")
-    if lockstep:
-        # identical on every rank (the norm of the all-reduced gradient): what a NaN anywhere did to this step
-        if not math.isfinite(st.read_scalar("gnorm_sq")):
-            return _fused_nan_return(st, optimizer, scheduler, fp16, loss_val, losses, times, x_t, means, targets, False)
-    elif math.isnan(loss_val):
+    if not lockstep and math.isnan(loss_val):
         # the device has skipped the update and cleared the arena (final micro-step), or the arena holds this micro-step's
         # NaNs on top of the earlier micro-steps' gradients, which the reference drops too (trainer.py:39, 66)
         return _fused_nan_return(st, optimizer, scheduler, fp16, loss_val, losses, times, x_t, means, targets, accumulate_gradient)
@@ -363,7 +360,48 @@ def _train_batch_fused(st, model, sample, optimizer, scheduler, logger, args, ac
             logger.add_scalar("train/Loss", loss_val)
             logger.add_scalar("lr", lr)
         scheduler.step()
+    if lockstep:
+        # What a NaN anywhere did to this step is in the norm of the all-reduced gradient, identical on every rank -- but
+        # it exists only when the whole step has run, and waiting for it here would cost the host its one-step lead over
+        # the GPU (measured: +3...5 ms per step).  So the host-side consequences above (scheduler.step(), EMA counter) are
+        # taken as if the step was applied, and corrected when the next call -- or optimizer.state_dict() -- finds that
+        # it was skipped (_settle): the reference's NaN branch (trainer.py:38-41: no scheduler step, no EMA update in
+        # bf16), one call late, on all ranks alike.
+        st.unsettled = (scheduler, ema_model, fp16)
+        if _STRICT_NAN:
+            _settle(st)
     return loss_val, losses, times, x_t, means, targets
+
+
+# MDM_HIP_STRICT_NAN=1: a synchronised multi-rank step waits for its own skip flag before it returns (exact reference
+# bookkeeping at every instant, at the price of the host's lead over the GPU)
+_STRICT_NAN = os.environ.get("MDM_HIP_STRICT_NAN", "0") == "1"
+
+
+def _settle(st):
+    """lock-step ranks: if the LAST synchronised step turned out skipped on the device (non-finite norm of the reduced
+    gradient), take back what the host did for it as if it had been applied: the EMA warm-up counter, and -- bf16 branch,
+    as the reference's NaN return -- the scheduler step.  Called at the start of the next train_batch and from the
+    optimizer's state_dict() hook, when the flag has long arrived (no stall)."""
+    pend = getattr(st, "unsettled", None)
+    if pend is None:
+        return
+    st.unsettled = None
+    if math.isfinite(st.read_scalar("gnorm_sq")):
+        return
+    scheduler, ema_model, fp16 = pend
+    if ema_model is not None:
+        ema_model.counter -= 1
+    if fp16:
+        # undo one scheduler.step(): schedulers whose rate is a function of last_epoch (LambdaLR and the closed-form ones)
+        closed = getattr(scheduler, "_get_closed_form_lr", None)
+        scheduler.last_epoch -= 1
+        if hasattr(scheduler, "_step_count"):
+            scheduler._step_count -= 1
+        lrs = closed() if closed is not None else scheduler.get_lr()
+        for g, lr in zip(scheduler.optimizer.param_groups, lrs):
+            g["lr"] = lr
+        scheduler._last_lr = [g["lr"] for g in scheduler.optimizer.param_groups]
 
 
 def _fused_nan_return(st, optimizer, scheduler, fp16, loss_val, losses, times, x_t, means, targets, clear):

@@ -279,8 +279,9 @@ def test_nan_on_one_rank_keeps_the_ranks_in_lockstep(tmp_path):
     """(advisor, rounds 3 and 4) bf16 fused step on two ranks, a NaN loss on rank 1 only: both ranks must skip the update
     (device side), keep identical parameters, and treat scheduler and EMA counter identically -- the reference's per-rank
     early return (trainer.py:38-41) would deadlock DDP.  Both ranks learn of the skip from the norm of the REDUCED gradient
-    and then do what the reference's NaN branch does (bf16: no scheduler.step(), no EMA-counter increment), so the learning
-    rate schedule and the EMA warm-up do not depend on the world size."""
+    -- when the next call finds it (no end-of-step wait: the host keeps its lead over the GPU) -- and then do what the
+    reference's NaN branch does (bf16: no scheduler.step(), no EMA-counter increment), so the learning rate schedule and
+    the EMA warm-up do not depend on the world size."""
     import math
 
     out = str(tmp_path / "r.pt")
