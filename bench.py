@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--no-reference-loop", action="store_true", help="skip the plain-path (torch optimizer / EMA / autograd accumulation) leg")
     ap.add_argument("--reference-loop", action="store_true", help="run the plain-path leg also when N > 1 (torch DDP, as the unchanged CLI)")
     ap.add_argument("--no-nested1024", action="store_true", help="skip the nested-1024 (configs[4]) sampling leg")
-    ap.add_argument("--wire-fp32", action="store_true", help="fp32 gradients on the wire (default with N > 1 over RCCL: bf16)")
+    ap.add_argument("--wire-fp32", action="store_true", help="fp32 gradients on the wire (the default)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="N = 1 only: run the gradient buckets through RCCL anyway (world-of-one process group)")
     ap.add_argument("--sample-batch", type=int, default=None)
@@ -261,7 +261,7 @@ def main():
     device = torch.device("cuda", local)
     batch = args.batch or {"unet64": 64, "nested256": 16, "mini": 4}[args.workload]
     bf16 = args.dtype == "bf16"
-    wire = torch.bfloat16 if args.wire_bf16 else (torch.float32 if args.wire_fp32 else "auto")   # auto: bf16 over RCCL when N > 1
+    wire = torch.bfloat16 if args.wire_bf16 else (torch.float32 if args.wire_fp32 else "auto")   # auto: fp32 (bf16 on the wire is opt-in)
 
     def sync():
         if world > 1:

@@ -23,11 +23,13 @@ torch DDP's reducer with a design sized for 8 x MI355X on point-to-point xGMI li
     exposed tail of the communication is one sub-millisecond collective, not a 256 MiB one;
   * the FIRST bucket is small too (``head_mb``, default 64 MiB = 4 % of the 64x64 U-Net's 1.66 GB of gradients): the
     links start working within the first tenth of backward instead of after a full 256 MiB has accumulated;
-  * the wire format follows the arithmetic of the step (``wire_dtype="auto"``): fp32 -- what the reference's DDP
-    reduces in -- unless the train step runs under bf16 autocast over RCCL (``note_autocast``, called by
-    ``train_batch``), where the gradients were computed from bf16 activations anyway and bf16 on the wire halves the
-    bytes per link.  The gradients are divided by the world size in fp32 BEFORE the cast; the cross-rank SUM itself then
-    runs in bf16 inside RCCL, the arena the optimizer reads is fp32.  Pass a dtype to pin either format;
+  * the wire format is fp32 by default (``wire_dtype="auto"`` = None = fp32: what the reference's DDP reduces in).
+    ``wire_dtype=torch.bfloat16`` halves the bytes per link -- the gradients are divided by the world size in fp32 and
+    cast in ONE pass into a persistent wire buffer, the cross-rank SUM then runs in bf16 inside RCCL, the arena the
+    optimizer reads stays fp32 -- but it is opt-in: the cast and the copy-back are 4.8 GB of extra HBM traffic per step
+    that compete with backward (measured in a world of one: +5 ms per step with 64 MiB buckets, against +2 ms for the
+    fp32 wire), while a 1.66 GB fp32 exchange (about 10 ms on a 7-link xGMI ring) hides under a 57 ms backward either
+    way; only the exposed tail (the late parameters, about 340 MB) would gain, about a millisecond;
   * ``record_timeline=True`` stamps every bucket's issue and completion with HIP events (``timeline()``), so the first
     run on a multi-GPU node shows how much of the exchange hid behind backward (``bench.py --gpus N`` prints it).
 
@@ -103,8 +105,7 @@ class GradReducer:
         if isinstance(wire_dtype, str):
             if wire_dtype != "auto":
                 raise ValueError("wire_dtype: a torch dtype, None (fp32) or 'auto'")
-            self._wire_auto = True      # fp32 until note_autocast(True) says the step computes in bf16
-            wire_dtype = None
+            wire_dtype = None           # "auto" = fp32, the reference's reduction precision
         self.wire_dtype = wire_dtype
         self._wire = {}                 # bucket -> persistent wire buffer (bf16 wire only)
         self._comm = None               # communication stream (GPU tensors, world > 1)
@@ -189,15 +190,9 @@ class GradReducer:
         self._count(p)
 
     def note_autocast(self, bf16: bool):
-        """``wire_dtype="auto"``: the step's compute dtype decides the wire format -- bf16 only for a bf16-autocast step on
-        GPU tensors over RCCL (gloo reduces bf16 slowly, and an fp32 step keeps the reference's fp32 reduction)."""
-        if not self._wire_auto or self._work:
-            return
-        nccl = dist.is_initialized() and str(dist.get_backend(self.group)).lower() == "nccl"
-        want = torch.bfloat16 if (bf16 and self.nranks > 1 and nccl and self.params and self.params[0].is_cuda) else None
-        if want != self.wire_dtype:
-            self.wire_dtype = want
-            self._wire = {}
+        """kept for callers of the round-4 interface: the wire format no longer follows the step's autocast (see the
+        module docstring: bf16 on the wire is an explicit choice)"""
+        return None
 
     def _comm_stream(self):
         if self._comm is None:
