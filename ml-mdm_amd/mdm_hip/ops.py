@@ -1811,9 +1811,26 @@ def adamw_ema_step(p, g, m, v, ema, gnorm_sq, lr, beta1, beta2, eps, weight_deca
 _dropout_rng = [None, 0]   # [seed, next Philox counter block]; seeded from torch's generator on first use
 
 
-def seed_dropout(seed: int):
-    """restart the dropout mask stream (default: torch.initial_seed() at the first call)"""
-    _dropout_rng[0], _dropout_rng[1] = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+def seed_dropout(seed: int, rank: int = None):
+    """restart the dropout mask stream.  Default seed (first use): ``torch.initial_seed()``; the data-parallel rank is
+    folded in (``rank`` default: torch.distributed's, else 0), so ranks that share a seed -- the reference seeds every
+    rank alike, clis/train_parallel.py -- still draw different masks for their different samples."""
+    if rank is None:
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+    _dropout_rng[0] = (int(seed) + 0x9E3779B97F4A7C15 * int(rank)) & 0xFFFFFFFFFFFFFFFF
+    _dropout_rng[1] = 0
+
+
+def get_dropout_rng_state():
+    """(seed, offset) of the dropout mask stream -- not part of torch's RNG state: save it next to
+    ``torch.cuda.get_rng_state()`` in a checkpoint if bit-reproducible resumption with dropout > 0 matters"""
+    if _dropout_rng[0] is None:
+        seed_dropout(torch.initial_seed())
+    return (_dropout_rng[0], _dropout_rng[1])
+
+
+def set_dropout_rng_state(state):
+    _dropout_rng[0], _dropout_rng[1] = int(state[0]) & 0xFFFFFFFFFFFFFFFF, int(state[1])
 
 
 class DropoutFn(torch.autograd.Function):
@@ -1843,6 +1860,8 @@ def dropout(x, p: float, training: bool = True):
     mask differs from torch's for the same seed -- as between any two generators -- the distribution is the same."""
     if not training or p <= 0.0:
         return x
+    if p >= 1.0:
+        return x * 0.0   # F.dropout(p = 1): everything dropped (the kernel's 1 / (1 - p) scale has no value there)
     if x.numel() % 8 != 0:
         raise _lib.MdmHipError("dropout: the element count must be a multiple of 8")
     return DropoutFn.apply(x, p)
