@@ -1302,7 +1302,9 @@ static int attn_bwd_launch(AttnArgs a, void* dkc, void* dvc, size_t dc_bs, int d
     const bool force_small = g_attn_bwd_mode == 2 || g_attn_bwd_mode == 3;
     if constexpr (D == 64 || D == 96) {
       // a wave owns 32 keys / queries (attn32.hpp): one pass over the resident tiles for all 256 rows of the level
-      if (a.L <= 256 && (!a.kc || a.S <= 32) && (a.B * a.H >= device_cus() || force_small) && !split_only && g_attn_bwd_mode != 3) {
+      // (at every batch size: with fewer heads than CUs -- the nested model's inner U-Net at batch 16 -- one block per head
+      // is still no slower than the 4 + 5 blocks per head of the streaming kernels: 65 against 73 us at B x H = 128)
+      if (a.L <= 256 && (!a.kc || a.S <= 32) && !split_only && g_attn_bwd_mode != 3) {
         constexpr int smem32 = attn_bwd_small32_lds<D>();
         ensure_dynamic_lds(attn_bwd_small32_kernel<D>, smem32);
         hipLaunchKernelGGL((attn_bwd_small32_kernel<D>), dim3(a.B * a.H), dim3(512), smem32, st, a);

@@ -549,12 +549,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
   const bool q_active = __builtin_amdgcn_readfirstlane(q0) < L;
   if (q_active) {
     const int qi = q0 + n;
-    bf16x8 qf[KS], gf[KS];
+    bf16x8 qf[KS], gf[KS];                   // (dO from global memory -- its image is staged at the switch; Q from its image)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      qf[s] = qsrc.frag(qi, s, hi);
-      gf[s] = gsrc.frag(qi, s, hi);
-    }
+    for (int s = 0; s < KS; ++s) gf[s] = gsrc.frag(qi, s, hi);
     float a, c;
     delta32<D>(gf, osrc, Ocp, p.o_rs, qi, qi < L, hi, a, c);
     const size_t lo = ((size_t)b * p.H + h) * L + (qi < L ? qi : 0);
@@ -567,6 +564,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
     }
     ATT_STAMP(2);
     __syncthreads();                         // (all 512 threads reach one of the two barriers of this if / else)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = lds_b128(R2 + q0 * PITCH + fo.b[s]);
 
     f32x16 dq[NB];
 #pragma unroll
@@ -596,6 +595,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
 
   // ---- switch: dO -> R0 ---------------------------------------------------------------------------------------------------
   ATT_STAMP(5);
+  // the operand fragments of phase K (this wave's 32 keys) come out of the K / V images while they are still in place
+  const int k0 = wave * 32;
+  const bool k_active = __builtin_amdgcn_readfirstlane(k0) < L;
+  bf16x8 kf[KS], vf[KS];
+  if (k_active) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kf[s] = lds_b128(R0 + k0 * PITCH + fo.b[s]);
+      vf[s] = lds_b128(R1 + k0 * PITCH + fo.b[s]);
+    }
+  }
   __syncthreads();                           // every wave is done with K, V, K_c, V_c
   ATT_STAMP(6);
   {
@@ -607,15 +617,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small32_kernel(AttnArgs p) {
   ATT_STAMP(7);
 
   // ---- phase K ----------------------------------------------------------------------------------------------------
-  const int k0 = wave * 32;
-  if (__builtin_amdgcn_readfirstlane(k0) < L) {
+  if (k_active) {
     const int key = k0 + n;
-    bf16x8 kf[KS], vf[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      kf[s] = ksrc.frag(key, s, hi);
-      vf[s] = vsrc.frag(key, s, hi);
-    }
     f32x16 dk[NB], dv[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) { dk[blk] = splat16(0.f); dv[blk] = splat16(0.f); }

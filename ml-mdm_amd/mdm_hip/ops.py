@@ -546,7 +546,7 @@ def profile_end(peak_tflops, peak_gbs=8000.0):
             table[k]["executed_tflops"] = round(v[3] / v[2] / 1e12, 1)
             table[k]["tflops_is"] = "credit for the dense 3x3 layer this sub-pixel kernel replaces (%.2fx the FLOPs it executes)" % (v[1] / v[3])
     dom = max(agg, key=lambda k: agg[k][2])
-    n, fl, t = agg[dom]
+    n, fl, t = agg[dom][:3]
     ach = fl / t / 1e12
     tot_f, tot_t = sum(v[1] for v in agg.values()), sum(v[2] for v in agg.values())
     return {
