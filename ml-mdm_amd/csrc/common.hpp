@@ -245,6 +245,43 @@ __device__ __forceinline__ float dgelu_f(float z) {
   gauss_cdf_pdf(z, c, p);
   return c + z * p;
 }
+// The same two functions for tensors stored in bf16.  The erf form above costs ~18 VALU instructions per element, two of
+// them transcendental (quarter rate), and the GELU epilogues of the FFN GEMMs pay for it: with the activation's arithmetic
+// removed altogether the FFN-up launch (768 -> 3072, batch 64) goes 117.6 -> 98.9 us, its x gelu'(aux) gradient 122.9 ->
+// 105.9, the train step 92.6 -> 90.9 ms (round 5, variant libraries, one call).  For a bf16 result nothing near 1e-7 is
+// needed, and the cheapest form has NO transcendental:
+//   Phi(z) ~ 0.5 + zc P(zc^2),  gelu'(z) ~ 0.5 + zc Q(zc^2),  zc = clamp(z, -4, 4),  P, Q of degree 7 in zc^2,
+// fitted minimax with zc P = zc Q = 0.5 exactly at zc = 4, so both saturate continuously at 1 / 0.  Evaluated in fp32 on
+// every bf16 input: max |error| 1.3e-4 for gelu, 5.1e-4 for gelu' -- relative L2 over N(0,1) inputs 3.4e-5 / 5.2e-4 against
+// 1.7e-3 for the bf16 rounding of the result itself; 12 / 10 plain VALU instructions.  Measured (A/B in one call): FFN-up
+// 113 -> 103-109 us, its gradient 120 -> 110, 512 -> 2048 at 32x32 251 -> 233 / 276 -> 253, train step -0.7 ... -0.9 ms.
+// (A sigmoid form z / (1 + 2^(-w(z))) with a fitted quintic w -- 9 instructions, v_exp + v_rcp among them, error 3e-5 --
+// bought only 0.2 ms: profiles/r05_did_not_pay.md #12.)  The fp32 kernels keep erf.
+__device__ __forceinline__ float odd_poly8(float zc, const float (&c)[8]) {
+  const float x2 = zc * zc;
+  float p = c[7];
+#pragma unroll
+  for (int k = 6; k >= 0; --k) p = fmaf(p, x2, c[k]);
+  return fmaf(zc, p, 0.5f);
+}
+__device__ __forceinline__ float gelu_poly(float z) {
+  constexpr float P[8] = {3.988065672e-01f, -6.606670007e-02f, 9.583257106e-03f, -1.021626672e-03f,
+                          7.628174443e-05f, -3.717267849e-06f, 1.047660447e-07f, -1.283420065e-09f};
+  const float cdf = fmaxf(odd_poly8(__builtin_amdgcn_fmed3f(z, -4.f, 4.f), P), 0.f);   // (rounding leaves -1e-6 at -4)
+  return z * cdf;                                  // (z, not the clamped value: exact identity above 4, NaN / inf stay)
+}
+__device__ __forceinline__ float dgelu_poly(float z) {
+  constexpr float Q[8] = {7.989620567e-01f, -2.662556930e-01f, 5.843304141e-02f, -8.376759832e-03f,
+                          7.867717586e-04f, -4.620522401e-05f, 1.525062443e-06f, -2.145770312e-08f};
+  return odd_poly8(__builtin_amdgcn_fmed3f(z, -4.f, 4.f), Q);
+}
+#if defined(MDM_GELU_EXACT)   // development A/B (tools/build_variant_gemm.sh): the erf form for bf16 tensors too
+template <typename T> __device__ __forceinline__ float gelu_t(float z) { return gelu_f(z); }
+template <typename T> __device__ __forceinline__ float dgelu_t(float z) { return dgelu_f(z); }
+#else
+template <typename T> __device__ __forceinline__ float gelu_t(float z) { return sizeof(T) == 2 ? gelu_poly(z) : gelu_f(z); }
+template <typename T> __device__ __forceinline__ float dgelu_t(float z) { return sizeof(T) == 2 ? dgelu_poly(z) : dgelu_f(z); }
+#endif
 
 // XCD-aware, bijective remap of a 1-D block id: consecutive logical ids land on
 // the same XCD (hardware places block b on XCD b % 8) so neighbouring tiles that

@@ -269,12 +269,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
       if (act == 1) {
         if (Ypre) *reinterpret_cast<uint4*>(Ypre + o) = raw[i];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) c.v[e] = gelu_f(c.v[e]);
+        for (int e = 0; e < EPV; ++e) c.v[e] = gelu_t<T>(c.v[e]);
       } else if (act == 2) {
         Chunk<T> ax;
         ax.load(reinterpret_cast<const T*>(&pre[i]));
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) c.v[e] *= dgelu_f(ax.v[e]);
+        for (int e = 0; e < EPV; ++e) c.v[e] *= dgelu_t<T>(ax.v[e]);
       }
       if (R) {
         Chunk<T> rr;
@@ -307,9 +307,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         if (p.bias) v[e] += p.bias[n + e];
         if (p.act == 1) {
           if (Ypre) Ypre[o + e] = from_f32<T>(v[e]);
-          v[e] = gelu_f(v[e]);
+          v[e] = gelu_t<T>(v[e]);
         } else if (p.act == 2) {
-          v[e] *= dgelu_f(to_f32(AUX[o + e]));
+          v[e] *= dgelu_t<T>(to_f32(AUX[o + e]));
         }
         if (R) v[e] += to_f32(R[o + e]);
         Y[o + e] = from_f32<T>(v[e]);
@@ -1888,10 +1888,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
       for (int e = 0; e < 4; ++e) ypre[idx + e] = from_f32<T>(v[e]);
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+    for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
   } else if (act == 2) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(to_f32(aux[idx + e]));
+    for (int e = 0; e < 4; ++e) v[e] *= dgelu_t<T>(to_f32(aux[idx + e]));
   }
   if (res) {
 #pragma unroll

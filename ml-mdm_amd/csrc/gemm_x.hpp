@@ -300,12 +300,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_x_kernel(ConvArgs p) {
       Chunk<T> c;                                                                                           \
       c.load(reinterpret_cast<const T*>(&r));                                                               \
       if constexpr (ACT == 1) {                                                                             \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) c.v[e] = gelu_f(c.v[e]);                              \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) c.v[e] = gelu_t<T>(c.v[e]);                              \
       } else {                                                                                              \
         Chunk<T> ax;                                                                                        \
         ax.load(reinterpret_cast<const T*>(&dr_op[(SL) % 3][q]));                                           \
         if constexpr (ACT == 2) {                                                                           \
-          _Pragma("unroll") for (int e = 0; e < 8; ++e) c.v[e] *= dgelu_f(ax.v[e]);                         \
+          _Pragma("unroll") for (int e = 0; e < 8; ++e) c.v[e] *= dgelu_t<T>(ax.v[e]);                         \
         } else {                                                                                            \
           _Pragma("unroll") for (int e = 0; e < 8; ++e) c.v[e] += ax.v[e];                                  \
         }                                                                                                   \
