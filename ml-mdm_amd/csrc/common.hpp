@@ -216,6 +216,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // v_rcp_f32 (1 ulp) instead of an IEEE division: "a / b" expands to an 11-instruction div_scale / div_fmas /
 // div_fixup sequence, which made the activation the most expensive part of the epilogues that apply it
 __device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
+// (the two transcendentals of SiLU are free where it is used: with silu / dsilu replaced by one multiply the GroupNorm kernels
+// -- HBM-bound -- leave the train step where it is, 92.3-92.8 against 92.6-92.7 ms; profiles/r05_did_not_pay.md #13)
 __device__ __forceinline__ float silu_f(float z) { return z * rcp_f(1.f + __expf(-z)); }
 // d silu(z) / dz
 __device__ __forceinline__ float dsilu_f(float z) {
