@@ -63,7 +63,8 @@ const char* mdm_last_error(void);
  * mdm_conv_wgrad + mdm_conv_wgrad_reduce: dw (Cout, Cin, k, k) fp32 = sum_m dy[m, :] (x) im2col(x)[m, :].
  *   The first call runs the split GEMM into fp32 slabs in ws (size from mdm_conv_wgrad_plan); the second sums the
  *   slabs into the reference OIHW layout.  want_bias / dbias != NULL additionally produce the bias gradient
- *   sum_m dy[m, :] (the bf16 kernel gets it from the dY fragments it already holds, via an all-ones MFMA operand).
+ *   sum_m dy[m, :] (the bf16 kernels get it from the dY fragments they already hold -- dot products against ones, dealt
+ *   out over the waves and k-tile blocks that hold the same fragments; partial rows + a row count live behind the slabs).
  * mdm_colsum: out[c] = sum_m x[m, c]  (bias gradients); ws from mdm_colsum_plan.
  *   `accumulate` != 0 (here and in mdm_gn_bwd / mdm_ln_bwd) adds the parameter gradient into the destination
  *   instead of overwriting it: the caller points it at the parameter's slot of a flat gradient arena, which

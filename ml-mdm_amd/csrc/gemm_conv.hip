@@ -775,11 +775,13 @@ struct WgradArgs {
   const void* x;    // [N, H, W, Cin]
   const void* dy;   // [M, Cout]
   float* slab;      // [splits][Cout][K]
-  float* bslab;     // [splits][Cout] column sums of dY (bias gradient partials) or null
+  float* bslab;     // [splits * share][Cout] column sums of dY (bias gradient partials) or null; the int at bslab[-WG_BHDR]
+                    // receives `share` (rows per split) from the kernel that fills the rows -- the reduce kernels read it
   int N, H, W, Cin, Ho, Wo, Cout, stride;
   int M, K;
   int splits, mtiles_per_split;
   int groups;       // conv_wgrad_bl_kernel only: > 0 = grouped launch over `groups` same-shape problems (WgradGroup)
+  int bias_share;   // conv_wgrad_bl_kernel: the column sums are spread over this many k-tile blocks of every (split, n-tile)
   int skip_cout;    // conv_wgrad_bl_kernel, 3x3 only: > 0 = dY is a 2x2-blocked gradient with skip_cout channels per phase
                     // (sub-pixel form of upsample2x -> conv3x3): output tile (phase, tap) is computed only for the four
                     // taps {ph, ph+1} x {pw, pw+1} its phase reads; the other tiles of the slab stay unwritten
@@ -791,6 +793,8 @@ struct WgradArgs {
 // weight-gradient time of a step).  26 of them together are 234-936 tiles: no split, no slabs, no reduce kernel, a
 // 256-k-tile loop per block, and the result is added straight into the parameters' gradient-arena slots.
 constexpr int WG_MAXG = 32;
+constexpr int WG_BHDR = 64;      // floats ahead of the bias-gradient partials: [0] = rows per split, as an int
+constexpr int WG_BSHARE = 4;     // most k-tile blocks of one (split, n-tile) the column sums are spread over
 struct WgradGroup {
   const void* x[WG_MAXG];
   const void* dy[WG_MAXG];
@@ -1282,6 +1286,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_tr_kernel(Wgrad
       if (n < p.Cout) p.bslab[(size_t)split * p.Cout + n] = bacc[i][0];
     }
   }
+  if (p.bslab != nullptr && blockIdx.x == 0 && tid == 0) reinterpret_cast<int*>(p.bslab - WG_BHDR)[0] = 1;   // one row per split
   float* __restrict__ S = p.slab + (size_t)split * p.Cout * p.K;
   const bool vec_ok = (p.K & 3) == 0;
 #pragma unroll
@@ -1341,6 +1346,17 @@ __device__ __forceinline__ float frag_sum(const Frag<bf16>& f, float acc) {
   const bf16x2 one = {(bf16)1.0f, (bf16)1.0f};
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{f.v[2 * q], f.v[2 * q + 1]}, one, acc, false);
+  return acc;
+}
+
+// the same sum as one opaque block: the compiler may not speculate it, so a wave-uniform `if` around it stays a scalar
+// branch (as plain code hipcc if-converts the four dot products + a v_cndmask into every wave's instruction stream)
+__device__ __forceinline__ float frag_sum_guarded(const Frag<bf16>& f, float acc) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  const u32x4_t r = __builtin_bit_cast(u32x4_t, f.v);
+  asm volatile("v_dot2c_f32_bf16 %0, 0x3f803f80, %1\n\tv_dot2c_f32_bf16 %0, 0x3f803f80, %2\n\t"
+               "v_dot2c_f32_bf16 %0, 0x3f803f80, %3\n\tv_dot2c_f32_bf16 %0, 0x3f803f80, %4"
+               : "+v"(acc) : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
   return acc;
 }
 
@@ -1445,12 +1461,27 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // (with tile skipping the first tile a phase computes is its first tap's, not tap 0's)
   const int bias_k0 = (MODE == MODE_3x3 && p.skip_cout > 0) ? (((n0 / p.skip_cout) >> 1) * 3 + ((n0 / p.skip_cout) & 1)) * p.Cin : 0;
-  const bool do_bias = (p.groups > 0 ? gr.bout[grp] != nullptr : p.bslab != nullptr) && k0 == bias_k0 && wn == 0;
-  // bias gradient = column sums of dY: the waves that own k-tile 0 add up the dY^T fragments they already hold
-  // (8 pixels of one channel per lane) with v_dot2c_f32_bf16 against (1, 1) -- one fp32 register per fragment row
-  float bsum[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) bsum[i] = 0.f;
+  // bias gradient = column sums of dY: a wave adds up dY^T fragments it already holds (8 pixels of one channel per lane)
+  // with v_dot2c_f32_bf16 against (1, 1) -- one fp32 register per fragment row.  A wave that sums all of its MT rows is
+  // ~30 % slower in that reduction tile, and when one k-tile block in tiles_k did that for all of its tiles the whole
+  // launch took +28 % (that block is the tail of a one-round launch; r05).  Every k-tile block of one (split, n-tile) and
+  // every wn wave of a block holds the SAME fragments, so the work is dealt out twice:
+  //   * wave wn sums only rows wn * BR .. wn * BR + BR - 1 of its MT (BR = MT / NWN = 2; the block's waves then cover
+  //     every channel exactly once -- no cross-wave sum), and
+  //   * k-tile block kt_rel of the first `share` sums only the kt_rel-th chunk of the split's reduction tiles: plain loop
+  //     up to the chunk, summing loop over it, accumulators written out (row split * share + kt_rel of bslab; the reduce
+  //     kernel adds the rows), plain loop for the rest -- the accumulators live in the summing loop only.  (Walking the
+  //     tiles in the same order as the other k-tile blocks matters: they stream the same dY rows through the XCD's L2;
+  //     a block that started at its chunk instead cost the launch +13-16 %.)
+  // Grouped launches add straight into the arena (one writer per channel): share = 1.
+  constexpr int BR = MT / NWN;
+  const int wn_s = __builtin_amdgcn_readfirstlane(wn);
+  const int bias_share = p.groups > 0 ? 1 : p.bias_share;
+  const int kt_rel = k0 >= bias_k0 ? (k0 - bias_k0) / BN : bias_share;
+  const bool bias_blk = (p.groups > 0 ? gr.bout[grp] != nullptr : p.bslab != nullptr) && kt_rel < bias_share;   // block-uniform
+  const int bias_chunk = (nt + bias_share - 1) / bias_share;
+  const int bias_b0 = bias_blk ? min(kt_rel * bias_chunk, nt) : nt;    // reduction tiles [bias_b0, bias_b1) are summed here
+  const int bias_b1 = bias_blk ? min(bias_b0 + bias_chunk, nt) : nt;
 
   unsigned fa[MT], fb[NT];
   {
@@ -1502,7 +1533,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ra[i][0]), "+v"(ra[i][1]) : "n"(WAITN) : "memory");     \
         const Frag<T> aq = frag_of(ra[i][0], ra[i][1]);                                                     \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) mma16(acc[i][j], bq[j], aq);                         \
-        if (BIAS) bsum[i] = frag_sum(aq, bsum[i]);                                                          \
+        if (BIAS && i / BR == wn_s) bsum[i % BR] = frag_sum_guarded(aq, bsum[i % BR]);                      \
         { const unsigned ad = fa[i] + so; MDM_TR2(ra[i][0], ra[i][1], ad, KS1); }                           \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
@@ -1518,7 +1549,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
       _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                      \
         const Frag<T> aq = frag_of(ra[i][0], ra[i][1]);                                                     \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) mma16(acc[i][j], bq[j], aq);                         \
-        if (BIAS) bsum[i] = frag_sum(aq, bsum[i]);                                                          \
+        if (BIAS && i / BR == wn_s) bsum[i % BR] = frag_sum_guarded(aq, bsum[i % BR]);                      \
         if (MT == 8) { MDM_WG_PIECE_RT(dst, i) } else { MDM_WG_PIECE_RT(dst, 2 * i) MDM_WG_PIECE_RT(dst, 2 * i + 1) } \
         { const unsigned ad = fa[i] + sn; MDM_TR2(ra[i][0], ra[i][1], ad, 0); }                             \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
@@ -1533,11 +1564,27 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
       case 6: MDM_WG_PIECE(stage, 6) break; default: MDM_WG_PIECE(stage, 7) break;                          \
     }
     // the two loop bodies execute the same number of barriers, so the waves of a block may take different ones
-    if (do_bias) {
-      for (int it = 0; it < nt; ++it) MDM_WG_ITER(true)
-    } else {
-      for (int it = 0; it < nt; ++it) MDM_WG_ITER(false)
+    // the two loop bodies execute the same number of barriers
+    int it = 0;
+    float bsum[BR];
+    for (; it < bias_b0; ++it) MDM_WG_ITER(false)
+#pragma unroll
+    for (int i = 0; i < BR; ++i) bsum[i] = 0.f;
+    for (; it < bias_b1; ++it) MDM_WG_ITER(true)
+    if (bias_blk) {
+#pragma unroll
+      for (int r = 0; r < BR; ++r) {
+        float v = bsum[r];                     // lanes l16, l16 + 16, + 32, + 48 hold the four pixel groups of a k-step
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int n = n0 + wm * TM + (wn * BR + r) * 16 + l16;
+        if (quad == 0 && n < p.Cout) {
+          if (p.groups > 0) gr.bout[grp][n] += v;   // splits == 1, share == 1: this wave is the only writer of channel n
+          else p.bslab[((size_t)split * bias_share + kt_rel) * p.Cout + n] = v;
+        }
+      }
     }
+    for (; it < nt; ++it) MDM_WG_ITER(false)
     // the fragments pre-read for the tile after the last are never used; retire them before the registers die
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #undef MDM_WG_PIECE_RT
@@ -1547,19 +1594,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
 #undef MDM_WG_TILE_STATE
 #undef MDM_BLDS
 
-  if (do_bias) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      float v = bsum[i];                       // lanes l16, l16 + 16, + 32, + 48 hold the four pixel groups of a k-step
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      const int n = n0 + wm * TM + i * 16 + l16;
-      if (quad == 0 && n < p.Cout) {
-        if (p.groups > 0) gr.bout[grp][n] += v;   // splits == 1: this block is the only writer of channel n
-        else p.bslab[(size_t)split * p.Cout + n] = v;
-      }
-    }
-  }
+  if (bias_blk && p.groups == 0 && split == 0 && kt_rel == 0 && n0 == 0 && tid == 0)
+    reinterpret_cast<int*>(p.bslab - WG_BHDR)[0] = bias_share;
   // grouped launches (splits == 1) add the finished tile straight into the layer's gradient-arena slot: every output
   // element has exactly one owner, so a plain read-modify-write suffices
   const bool direct = p.groups > 0;
@@ -1586,10 +1622,42 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
 }
 #undef MDM_TR2
 
+// Bias-gradient part of the reduce kernels: dbias[o] (+)= sum over the splits * share rows of partials (share: the int the
+// producing kernel left at bslab[-WG_BHDR]).  32 channels per block, the rows dealt to the block's NT / 32 thread groups
+// (fixed order -> reproducible), the groups' sums added up through LDS.
+template <int NT>
+__device__ __forceinline__ void wgrad_bias_reduce(const float* __restrict__ bslab, float* __restrict__ dbias, int splits,
+                                                  int Cout, int accumulate, int blk, float* lds) {
+  constexpr int G = NT / 32;
+  const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
+  const int rows = splits * reinterpret_cast<const int*>(bslab - WG_BHDR)[0];
+  const int o = blk * 32 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (o < Cout) {
+    const float* src = bslab + o;
+    int r = g;
+    for (; r + 3 * G < rows; r += 4 * G) {
+      s0 += src[(size_t)r * Cout];
+      s1 += src[(size_t)(r + G) * Cout];
+      s2 += src[(size_t)(r + 2 * G) * Cout];
+      s3 += src[(size_t)(r + 3 * G) * Cout];
+    }
+    for (; r < rows; r += G) s0 += src[(size_t)r * Cout];
+  }
+  lds[tid] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && o < Cout) {
+    float s = lds[c];
+#pragma unroll
+    for (int q = 1; q < G; ++q) s += lds[q * 32 + c];
+    dbias[o] = accumulate ? dbias[o] + s : s;
+  }
+}
+
 // dW_oihw[o][i][t] = sum_s slab[s][o][t*Cin + i]      (taps = 1 or 9)
 // One block per (o, 64-channel block): the 9 x 64 slab values are read as 9 contiguous runs, transposed through
-// LDS and written as one contiguous run of 576 floats, so both sides are coalesced.  Blocks beyond the weight
-// grid reduce the bias-gradient partials bslab[s][o].
+// LDS and written as one contiguous run of 576 floats, so both sides are coalesced.  The first `bblocks` blocks of the
+// grid reduce the bias-gradient partials (wgrad_bias_reduce).
 // Round 4: this kernel read its slabs at 0.5 TB/s (66 MB in 133 us per 3x3 layer of the 64x64 level, 5.3 ms per step):
 // 4 output channels per 256-thread block meant 256 blocks for a 256 x 256 layer, each thread walking three groups one
 // after the other with four loads in flight.  Now ONE output channel per block (taps x 16 = 144 active lanes, one 16-byte
@@ -1597,20 +1665,16 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
 __global__ __launch_bounds__(192) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                            const float* __restrict__ bslab, float* __restrict__ dbias,
                                                            int splits, int Cout, int Cin, int taps, int accumulate,
-                                                           int wblocks) {
+                                                           int bblocks) {
   __shared__ float tile[64 * 9 + 4];
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= wblocks) {   // bias part: 192 output channels per block
-    const int o = ((int)blockIdx.x - wblocks) * 192 + tid;
-    if (o < Cout) {
-      float s = 0.f;
-      for (int sp = 0; sp < splits; ++sp) s += bslab[(size_t)sp * Cout + o];
-      dbias[o] = accumulate ? dbias[o] + s : s;
-    }
+  if ((int)blockIdx.x < bblocks) {   // bias part first (its blocks walk splits * share rows): 32 output channels per block
+    wgrad_bias_reduce<192>(bslab, dbias, splits, Cout, accumulate, (int)blockIdx.x, tile);
     return;
   }
+  const int wb = (int)blockIdx.x - bblocks;
   const int iblocks = (Cin + 63) / 64;
-  const int o = blockIdx.x / iblocks, i0 = (blockIdx.x - o * iblocks) * 64;
+  const int o = wb / iblocks, i0 = (wb - o * iblocks) * 64;
   const int ni = min(64, Cin - i0);            // Cin % 4 == 0 (host-checked) -> ni % 4 == 0
   const size_t total = (size_t)Cout * Cin * taps;
   const int K = Cin * taps;
@@ -1639,25 +1703,21 @@ __global__ __launch_bounds__(192) void wgrad_reduce_kernel(const float* __restri
   for (int r = tid; r < run; r += 192) dst[r] = accumulate ? dst[r] + tile[r] : tile[r];
 }
 
-// taps == 1: packed and reference layouts coincide -> flat, fully coalesced reduction (grid-stride); the last
+// taps == 1: packed and reference layouts coincide -> flat, fully coalesced reduction (grid-stride); the first
 // `bblocks` blocks reduce the bias partials
 __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                                 const float* __restrict__ bslab,
                                                                 float* __restrict__ dbias, int splits, int Cout,
-                                                                size_t total, int accumulate, int wblocks) {
-  if ((int)blockIdx.x >= wblocks) {
-    const int o = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
-    if (o < Cout) {
-      float s = 0.f;
-      for (int sp = 0; sp < splits; ++sp) s += bslab[(size_t)sp * Cout + o];
-      dbias[o] = accumulate ? dbias[o] + s : s;
-    }
+                                                                size_t total, int accumulate, int wblocks, int bblocks) {
+  if ((int)blockIdx.x < bblocks) {
+    __shared__ float part[256];
+    wgrad_bias_reduce<256>(bslab, dbias, splits, Cout, accumulate, (int)blockIdx.x, part);
     return;
   }
   const size_t n4 = total / 4;   // Cin % 4 == 0 -> total % 4 == 0
   const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
   f32x4* d4 = reinterpret_cast<f32x4*>(dw);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)wblocks * 256) {
+  for (size_t i = (size_t)(blockIdx.x - bblocks) * 256 + threadIdx.x; i < n4; i += (size_t)wblocks * 256) {
     f32x4 a0 = s4[i], a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
     int sp = 1;
     for (; sp + 4 <= splits; sp += 4) {   // four independent loads in flight per lane
@@ -2798,6 +2858,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WgDirectArgs p) {
       if (quad == 0) p.bslab[(size_t)blockIdx.x * COUT + (mw * 2 + mi) * 16 + l15] = v;
     }
   }
+  if (p.bslab != nullptr && blockIdx.x == 0 && tid == 0) reinterpret_cast<int*>(p.bslab - WG_BHDR)[0] = 1;   // one row per slab
 }
 
 // slabs (= blocks) of the direct kernel for a problem, 0 = not a shape it is built for.  Decided from (M, Cout, K) alone so
@@ -2877,7 +2938,8 @@ extern "C" int mdm_conv_wgrad_plan(int M, int Cout, int K, int dtype, int* split
   wgrad_choose(M, Cout, K, dtype, &te, &splits);
   *splits_out = splits;
   // weight slabs + bias-gradient partials (or the column-sum workspace of the fp32 path)
-  *ws_bytes = ((size_t)splits * Cout * K + (size_t)(splits > 64 ? splits : 64) * Cout) * sizeof(float);
+  const int brows = splits * WG_BSHARE > 64 ? splits * WG_BSHARE : 64;
+  *ws_bytes = ((size_t)splits * Cout * K + WG_BHDR + (size_t)brows * Cout) * sizeof(float);
   return 0;
 }
 
@@ -2912,9 +2974,13 @@ static int conv_wgrad_impl(const void* x, const void* dy, int want_bias, float* 
   const int mt_total = (a.M + bkm - 1) / bkm;
   a.mtiles_per_split = (mt_total + a.splits - 1) / a.splits;
   float* const bias_ws = ws + (size_t)a.splits * Cout * a.K;
-  a.bslab = (want_bias && dtype == DT_BF16) ? bias_ws : nullptr;   // the bf16 kernels fold the column sums in
+  a.bslab = (want_bias && dtype == DT_BF16) ? bias_ws + WG_BHDR : nullptr;   // the bf16 kernels fold the column sums in
   const int te = wgrad_tile(a.M, Cout, a.K, dtype);
   const int tiles = ((Cout + te - 1) / te) * ((a.K + te - 1) / te);
+  {   // k-tile blocks that share the column sums: those of the whole row of tiles, or of a phase's first tap (blocked form)
+    const int kt = skip_cout > 0 ? Cin / te : (a.K + te - 1) / te;
+    a.bias_share = kt < WG_BSHARE ? (kt < 1 ? 1 : kt) : WG_BSHARE;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (wgrad_direct_slabs(a.M, Cout, a.K, dtype) && wgrad_direct_ok(a, ksize)) {
     return launch_wgrad_direct<64, 9, 8>(a, st);
@@ -3042,18 +3108,17 @@ extern "C" int mdm_conv_wgrad_reduce(const float* ws, float* dw_oihw, float* dbi
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* const bias_ws = const_cast<float*>(ws) + (size_t)splits * Cout * K;
-  const float* bslab = (dbias && dtype == DT_BF16) ? bias_ws : nullptr;
-  int bblocks = bslab ? (Cout + 255) / 256 : 0;
+  const float* bslab = (dbias && dtype == DT_BF16) ? bias_ws + WG_BHDR : nullptr;
+  const int bblocks = bslab ? (Cout + 31) / 32 : 0;
   if (ksize == 1) {
     const size_t total = (size_t)Cout * Cin;
     const int wblocks = (int)((total / 4 + 255) / 256 > 2048 ? 2048 : (total / 4 + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, ws, dw_oihw, bslab, dbias,
-                       splits, Cout, total, accumulate, wblocks);
+                       splits, Cout, total, accumulate, wblocks, bblocks);
   } else {
     const int wblocks = Cout * ((Cin + 63) / 64);
-    bblocks = bslab ? (Cout + 191) / 192 : 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(192), 0, st, ws, dw_oihw, bslab, dbias,
-                       splits, Cout, Cin, ksize * ksize, accumulate, wblocks);
+                       splits, Cout, Cin, ksize * ksize, accumulate, bblocks);
   }
   if (dbias && !bslab) {
     MDM_CHECK_ARG(dy);

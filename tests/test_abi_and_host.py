@@ -29,8 +29,8 @@ def test_plan_functions_are_host_only():
     L = _lib.lib()
     splits, ws = ctypes.c_int(0), ctypes.c_size_t(0)
     assert L.mdm_conv_wgrad_plan(64 * 64 * 64, 256, 2304, 1, ctypes.byref(splits), ctypes.byref(ws)) == 0
-    # weight slabs + bias-gradient partials
-    assert splits.value >= 1 and ws.value == (splits.value * 256 * 2304 + max(splits.value, 64) * 256) * 4
+    # weight slabs + a 64-float header + bias-gradient partials (up to 4 rows per split)
+    assert splits.value >= 1 and ws.value == (splits.value * 256 * 2304 + 64 + max(4 * splits.value, 64) * 256) * 4
     assert L.mdm_gn_plan(4, 256, 768, 32, ctypes.byref(ws)) == 0 and ws.value > 0
     # invalid arguments are reported, not executed
     assert L.mdm_conv_wgrad_plan(1, 1, 1, 1, None, None) < 0

@@ -83,6 +83,10 @@ def main():
         if what in ("wgrad", "all"):
             t = timeit(lambda: ops._wgrad_launch(x, y, B, H, H, cin, Ho, Ho, cout, ks, stride))
             line += "  wgrad %7.3f ms %7.1f TF" % (t * 1e3, flops / t / 1e12)
+            if os.environ.get("KB_DBIAS") == "1":     # the same launch also producing the bias gradient (column sums of dY)
+                db = torch.empty(cout, device=dev)
+                t = timeit(lambda: ops._wgrad_launch(x, y, B, H, H, cin, Ho, Ho, cout, ks, stride, dbias=db))
+                line += "  +dbias %7.3f ms" % (t * 1e3)
         print(line, flush=True)
     if what in ("rotate",):
         # the store-heavy 1x1 GEMMs with FRESH output buffers every launch (a ring of `KB_RING` buffers larger than the
