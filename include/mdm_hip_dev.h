@@ -25,12 +25,16 @@ int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype);
  *   8  1 = the narrow weight gradients (64 output channels, >= 262144 pixels) go back to the split GEMM (no wgrad_direct_kernel)
  *   9  forward split-K: minimum k-tiles per range (default 6);  10: minimum k-tiles of serial walk a split must save (default 16)
  *  11  1 = no 4-stage instantiations of conv_gemm_bl_kernel<128, 128> for under-filled grids (small-batch sampling)
- *  12  forward split-K: blocks per CU a split aims for (0 = by problem size: 1 for M <= 2048, else 2) */
+ *  12  forward split-K: blocks per CU a split aims for (0 = by problem size: 1 for M <= 2048, else 2)
+ *  13  1 = mdm_conv_wgrad_reduce launches nothing (timing-only ablation: what the slab-reduce launches cost a step; WRONG gradients) */
 int mdm_dev_set_knob(int idx, int value);
 /* attention backward kernel choice: 0 = by shape, 1 = always the split (dQ + dK/dV) kernels on 16x16x32 MFMAs, 2 = the
  * one-block-per-head kernel whenever the shape allows (tests), 3 = as 2 but the 16x16x32 one, 4 = the streaming kernels on
  * 32x32x16 MFMAs (csrc/attn32.hpp) whenever the shape allows */
 int mdm_dev_set_attn_bwd(int mode);
+/* attention forward kernel choice: 0 = by shape, 1 = always the 16x16x32-MFMA kernel, 2 = the 32x32x16 kernel of
+ * csrc/attn32.hpp whenever the shape allows (bf16, d = 64 / 96, at most 32 text keys) */
+int mdm_dev_set_attn_fwd(int mode);
 /* phase time stamps of attn_bwd_small32_kernel: a device buffer of [blocks][8][16] 64-bit words (tools/attn_debug.py), or
  * null (the default) */
 int mdm_dev_set_attn_dbg(void* buf);

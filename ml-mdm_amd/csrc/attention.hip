@@ -1232,9 +1232,29 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
 
 using namespace mdm;
 
+// development knob (mdm_hip_dev.h): forward kernel choice, 0 = by shape, 1 = always attn_fwd_kernel (16x16x32 MFMAs),
+// 2 = attn_fwd32_kernel (csrc/attn32.hpp) whenever it can express the problem
+static int g_attn_fwd_mode = 0;
+extern "C" int mdm_dev_set_attn_fwd(int mode) {
+  if (mode < 0 || mode > 2) return -1;
+  g_attn_fwd_mode = mode;
+  return 0;
+}
+
 template <typename T, int D, bool SPLIT = false>
 static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   using G = AttnGeom<T, D>;
+  if constexpr (sizeof(T) == 2 && !SPLIT && (D == 64 || D == 96)) {
+    // a wave owns 32 queries on 32x32x16 MFMAs (half the LDS bytes per FLOP): bf16, at most one tile of text keys, and
+    // enough (batch, head, 128-query) blocks for the chip -- the small-batch sampler keeps the 16-queries-per-wave form below
+    const long blocks = (long)((a.L + 127) / 128) * a.B * a.H;
+    const bool can = !a.kc || (a.S <= 32 && a.out_cross);   // the cross part is staged through out_cross
+    if (can && g_attn_fwd_mode != 1 && (g_attn_fwd_mode == 2 || blocks >= device_cus())) {
+      ensure_dynamic_lds(attn_fwd32_kernel<D>, attn_fwd32_lds<D>());
+      hipLaunchKernelGGL(attn_fwd32_kernel<D>, dim3((a.L + 127) / 128, a.B * a.H), dim3(256), attn_fwd32_lds<D>(), st, a);
+      MDM_LAUNCH_STATUS();
+    }
+  }
   constexpr int smem = sizeof(T) == 2 ? 4 * G::NAT_BYTES : G::NAT_BYTES + (G::NAT_BYTES > G::TR_BYTES ? G::NAT_BYTES : G::TR_BYTES);
   ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, true, SPLIT>, smem);
   ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, false, SPLIT>, smem);

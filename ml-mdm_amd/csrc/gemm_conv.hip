@@ -2692,8 +2692,10 @@ extern "C" int mdm_linear_grouped(const void* const* x, const void* const* w_pac
   return launch_conv_bl_grouped<128, 128, 2, 2>(a, gr, st);
 }
 
+static int g_skip_wgrad_reduce = 0;   // development knob 13: timing-only ablation, the slab reduces are not launched (WRONG gradients)
 extern "C" int mdm_dev_set_knob(int idx, int value) {
-  MDM_CHECK_ARG(idx >= 0 && idx < 13);
+  MDM_CHECK_ARG(idx >= 0 && idx < 14);
+  if (idx == 13) { g_skip_wgrad_reduce = value; return 0; }
   if (idx == 12) { g_split_per_cu = value > 0 ? value : 0; return 0; }
   if (idx == 11) { g_no_deep_pipe = value; return 0; }
   if (idx == 8) { g_no_wgrad_direct = value; return 0; }
@@ -3102,6 +3104,7 @@ extern "C" int mdm_conv_wgrad_grouped(const void* const* x, const void* const* d
 extern "C" int mdm_conv_wgrad_reduce(const float* ws, float* dw_oihw, float* dbias, const void* dy, int M, int Cin,
                                      int Cout, int ksize, int accumulate, int dtype, void* stream) {
   MDM_CHECK_ARG(ws && dw_oihw && (ksize == 1 || ksize == 3));
+  if (g_skip_wgrad_reduce) return 0;
   const int K = ksize * ksize * Cin;
   int splits; size_t wsb;
   int rc = mdm_conv_wgrad_plan(M, Cout, K, dtype, &splits, &wsb);

@@ -424,13 +424,13 @@ __device__ __forceinline__ float rows_sum(float v) {   // sum over the lanes of 
   return v;
 }
 
-template <typename T, int ACT, int NI, int NTHR>
+template <typename T, int ACT, int NI, int NTHR, int LPR = GnF<T>::LPR>
 __global__ __launch_bounds__(NTHR) void gn_fused_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const T* __restrict__ film,
                                                             T* __restrict__ y, float* __restrict__ stats,
                                                             float* __restrict__ coef, int HW, int C, int G, int CB,
                                                             float eps) {
-  constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = NTHR / LPR, NW = NTHR / 64;
+  constexpr int EPV = Tr<T>::EPV, R = NTHR / LPR, NW = NTHR / 64;
   __shared__ float sh[NW][LPR];
   __shared__ float gmean[8], grstd[8];
   const int n = blockIdx.x, cb0 = blockIdx.y * CB;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(NTHR) void gn_fused_fwd_kernel(const T* __restrict_
   }
 }
 
-template <typename T, int ACT, int NI, int NTHR>
+template <typename T, int ACT, int NI, int NTHR, int LPR = GnF<T>::LPR>
 __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const T* __restrict__ film, const float* __restrict__ stats,
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
                                                             float* __restrict__ dbeta, const T* __restrict__ dres,
                                                             const T* __restrict__ dres2,
                                                             int HW, int C, int G, int CB, int pstride) {
-  constexpr int EPV = Tr<T>::EPV, LPR = GnF<T>::LPR, R = NTHR / LPR, NW = NTHR / 64;
+  constexpr int EPV = Tr<T>::EPV, R = NTHR / LPR, NW = NTHR / 64;
   __shared__ float sh[NW][LPR][2 * EPV];
   __shared__ float tot[LPR][2 * EPV];
   __shared__ float sg[LPR][2];
@@ -556,6 +556,9 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
     b[e] = coef[((size_t)n * C + ch0 + e) * 2 + 1];
   }
   uint4 rx[NI], rd[NI];   // x and dy of the slice, storage format
+  // (the residual-branch gradients are read in the store loop, after the two block-wide reductions.  Requesting them up here
+  // with x and dy -- 16 more registers, three waves per SIMD instead of four -- was slower on cold buffers: 43 / 83 us against
+  // 36 / 67 at 16x16, C = 768 / 1536; r05)
   float A1[EPV], A2[EPV];
 #pragma unroll
   for (int e = 0; e < EPV; ++e) { A1[e] = 0.f; A2[e] = 0.f; }
@@ -584,8 +587,8 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
     for (int e = 0; e < EPV; ++e) { sh[wave][lane][e] = A1[e]; sh[wave][lane][EPV + e] = A2[e]; }
   }
   __syncthreads();
-  if (tid < LPR * 2 * EPV) {
-    const int cc = tid / (2 * EPV), e2 = tid % (2 * EPV);
+  for (int i = tid; i < LPR * 2 * EPV; i += NTHR) {
+    const int cc = i / (2 * EPV), e2 = i % (2 * EPV);
     float t = 0.f;
     for (int w = 0; w < NW; ++w) t += sh[w][cc][e2];
     tot[cc][e2] = t;
@@ -659,15 +662,33 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
   }
 }
 
-// channels per block of the fused kernels (0 = not applicable -> three-kernel path)
-static int gn_fused_cb(int HW, int C, int G, int dtype, int max_ni) {
+// Shape of a fused launch: channels per block (cb: whole groups, <= 8 of them), block size and passes.  cb = 0: not
+// applicable -> three-kernel path.
+// (Tried in round 5 for the 24 / 48-channel groups of C = 768 / 1536, whose 8 chunk lanes hold 48 channels = 96-byte row
+// pieces with two lanes idle: blocks of 32 chunk lanes = 192 channels = 384-byte pieces on 128-byte boundaries.  Not
+// faster on cold buffers -- backward 37 / 72 against 35 / 67 us at 16x16, forward 24 / 53 against 18 / 37: neighbouring
+// blocks run together and share their lines in L2, and four times fewer blocks hide less latency.)
+struct GnFusedCfg { int cb, nthr, ni; };
+static GnFusedCfg gn_fused_cfg(int HW, int C, int G, int dtype, bool bwd) {
   const int epv = dtype == DT_F32 ? 4 : 8, lpr = dtype == DT_F32 ? 16 : 8;
   const int cpg = C / G;
-  if (cpg % epv != 0 || cpg > lpr * epv) return 0;
-  if (HW > max_ni * (1024 / lpr)) return 0;
+  GnFusedCfg f = {0, 0, 0};
+  if (cpg % epv != 0 || cpg > lpr * epv) return f;
   int gpb = (lpr * epv) / cpg;
   while (gpb > 1 && (G % gpb != 0 || gpb > 8)) --gpb;
-  return cpg * gpb;
+  const int cb = cpg * gpb;
+  // forward: x in registers (4 per pass); backward: x AND dy (8 per pass).  Smallest block that covers the image.
+  // The backward's 16 passes of a 512-thread block (read once instead of the three-kernel path's twice) pay where the
+  // row pieces are whole 128-byte lines: 32x32 level, cold buffers, C = 512 / 1024: 77 / 145 us against 85 / 170;
+  // C = 768 / 1280 (96- / 80-byte pieces): 138 / 266 against 131 / 243.
+  static const int fwd_opts[][2] = {{256, 8}, {512, 8}, {1024, 8}};
+  static const int bwd_opts[][2] = {{512, 4}, {1024, 4}, {512, 16}};
+  const int (*opts)[2] = bwd ? bwd_opts : fwd_opts;
+  for (int i = 0; i < 3; ++i) {
+    if (opts[i][1] == 16 && !(dtype == DT_BF16 && cb % 64 == 0)) continue;
+    if (HW <= opts[i][1] * (opts[i][0] / lpr)) { f.cb = cb; f.nthr = opts[i][0]; f.ni = opts[i][1]; return f; }
+  }
+  return f;
 }
 
 // ---------------------------------------------------------------------------------
@@ -898,17 +919,19 @@ extern "C" int mdm_gn_fwd(const void* x, const float* gamma, const float* beta, 
   MDM_CHECK_ARG(C % epv == 0 && C % G == 0 && C <= 2048 && G <= 256);
   MDM_CHECK_ARG(act == 0 || act == 1);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (const int cb = gn_fused_cb(HW, C, G, dtype, 8)) {
-    const dim3 grid(N, C / cb);
-    const int lpr = dtype == DT_F32 ? 16 : 8;
-    const int nthr = HW <= 8 * (256 / lpr) ? 256 : HW <= 8 * (512 / lpr) ? 512 : 1024;   // smallest block with <= 8 passes
-#define MDM_GN_FUSED_FWD(TT, ACT)                                                                                  \
-    if (nthr == 256) hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, 8, 256>), grid, dim3(256), 0, st, (const TT*)x, gamma, beta, (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps); \
-    else if (nthr == 512) hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, 8, 512>), grid, dim3(512), 0, st, (const TT*)x, gamma, beta, (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps); \
-    else hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, 8, 1024>), grid, dim3(1024), 0, st, (const TT*)x, gamma, beta, (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps)
-    if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_FWD(float, 1); } else { MDM_GN_FUSED_FWD(float, 0); } }
-    else { if (act) { MDM_GN_FUSED_FWD(bf16, 1); } else { MDM_GN_FUSED_FWD(bf16, 0); } }
+  if (const GnFusedCfg f = gn_fused_cfg(HW, C, G, dtype, false); f.cb) {
+    const dim3 grid(N, C / f.cb);
+    const int cb = f.cb;
+#define MDM_GN_FUSED_FWD_L(TT, ACT, NI_, NT_, LPR_)                                                                 \
+    hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, ACT, NI_, NT_, LPR_>), grid, dim3(NT_), 0, st, (const TT*)x, gamma, beta, (const TT*)film, (TT*)y, stats, coef, HW, C, G, cb, eps)
+#define MDM_GN_FUSED_FWD(TT, ACT, LPR_)                                                                             \
+    if (f.nthr == 256) MDM_GN_FUSED_FWD_L(TT, ACT, 8, 256, LPR_);                                                  \
+    else if (f.nthr == 512) MDM_GN_FUSED_FWD_L(TT, ACT, 8, 512, LPR_);                                             \
+    else MDM_GN_FUSED_FWD_L(TT, ACT, 8, 1024, LPR_)
+    if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_FWD(float, 1, 16); } else { MDM_GN_FUSED_FWD(float, 0, 16); } }
+    else { if (act) { MDM_GN_FUSED_FWD(bf16, 1, 8); } else { MDM_GN_FUSED_FWD(bf16, 0, 8); } }
 #undef MDM_GN_FUSED_FWD
+#undef MDM_GN_FUSED_FWD_L
     MDM_LAUNCH_STATUS();
   }
   const int slabs = gn_slabs(N, HW);
@@ -950,17 +973,20 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
       return (int)hipGetLastError();
     }
   }
-  // x AND dy stay in registers here: 4 passes at most (beyond that the register file spills; two-kernel path)
-  if (const int cb = gn_fused_cb(HW, C, G, dtype, 4)) {
-    const dim3 grid(N, C / cb);
-    const int lpr = dtype == DT_F32 ? 16 : 8;
-    const int nthr = HW <= 4 * (512 / lpr) ? 512 : 1024;
-#define MDM_GN_FUSED_BWD(TT, ACT)                                                                                  \
-    if (nthr == 512) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 512>), grid, dim3(512), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, dgamma, dbeta, (const TT*)dres, (const TT*)dres2, HW, C, G, cb, pstride); \
-    else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, 4, 1024>), grid, dim3(1024), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, dgamma, dbeta, (const TT*)dres, (const TT*)dres2, HW, C, G, cb, pstride)
-    if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_BWD(float, 1); } else { MDM_GN_FUSED_BWD(float, 0); } }
-    else { if (act) { MDM_GN_FUSED_BWD(bf16, 1); } else { MDM_GN_FUSED_BWD(bf16, 0); } }
+  // x AND dy stay in registers here: 4 passes with 1024 threads, up to 16 with 512 (8 registers per pass)
+  if (const GnFusedCfg f = gn_fused_cfg(HW, C, G, dtype, true); f.cb) {
+    const dim3 grid(N, C / f.cb);
+    const int cb = f.cb;
+#define MDM_GN_FUSED_BWD_L(TT, ACT, NI_, NT_, LPR_)                                                                 \
+    hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, ACT, NI_, NT_, LPR_>), grid, dim3(NT_), 0, st, (const TT*)dy, (const TT*)x, gamma, beta, (const TT*)film, stats, coef, (TT*)dx, (TT*)dfilm, dgamma, dbeta, (const TT*)dres, (const TT*)dres2, HW, C, G, cb, pstride)
+#define MDM_GN_FUSED_BWD(TT, ACT, LPR_)                                                                             \
+    if (f.nthr == 512 && f.ni == 4) MDM_GN_FUSED_BWD_L(TT, ACT, 4, 512, LPR_);                                     \
+    else if (f.nthr == 512) MDM_GN_FUSED_BWD_L(TT, ACT, 16, 512, LPR_);                                            \
+    else MDM_GN_FUSED_BWD_L(TT, ACT, 4, 1024, LPR_)
+    if (dtype == DT_F32) { if (act) { MDM_GN_FUSED_BWD(float, 1, 16); } else { MDM_GN_FUSED_BWD(float, 0, 16); } }
+    else { if (act) { MDM_GN_FUSED_BWD(bf16, 1, 8); } else { MDM_GN_FUSED_BWD(bf16, 0, 8); } }
 #undef MDM_GN_FUSED_BWD
+#undef MDM_GN_FUSED_BWD_L
     MDM_LAUNCH_STATUS();
   }
   const int slabs = gn_slabs(N, HW);

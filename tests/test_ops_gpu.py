@@ -451,9 +451,10 @@ def test_ffn(dtype):
     (2, 49, 1280, 32, False, False),
     (2, 1024, 64, 32, False, True),    # 2 channels / group
     # whole chunks per group and a small image: the single-kernel (register-resident) GroupNorm
-    (2, 1024, 512, 32, True, True),    # 16 / group, 8 passes forward; backward falls back to three kernels (bf16)
+    (2, 1024, 512, 32, True, True),    # 16 / group, 8 passes forward; backward 16 passes of a 512-thread block (bf16)
     (3, 256, 512, 32, False, False),   # no activation
     (2, 400, 1536, 32, True, True),    # 48 / group (one group per block), 4 passes
+    (2, 256, 1536, 32, True, True),    # 48 / group at the 16x16 level's size
     (2, 256, 256, 32, False, True),    # 8 / group, 8 groups per block
     # large images: partial -> apply with the per-block finalize of a channel slice
     (2, 4096, 256, 32, True, True),    # the 64x64 level: 64-channel slices, 8 groups each
@@ -636,6 +637,20 @@ def test_attention(dtype, B, L, S, H, d, masked, request):
     if S:
         assert relerr(kd.grad.float().cpu(), kvc.grad) < tol
     if dtype == torch.bfloat16:
+        # both forward kernels on the same case (mdm_hip_dev.h: 1 = 16x16x32 MFMAs, 2 = the 32x32x16 kernel of
+        # csrc/attn32.hpp where the shape allows), with the saved lse feeding the default backward
+        for fmode in (1, 2):
+            _lib.lib().mdm_dev_set_attn_fwd(fmode)
+            request.addfinalizer(lambda: _lib.lib().mdm_dev_set_attn_fwd(0))
+            qd1 = qkv.detach().to(dtype).to(dev()).requires_grad_()
+            kd1 = kvc.detach().to(dtype).to(dev()).requires_grad_() if S else None
+            o1 = ops.attention(qd1, kd1, md, H)
+            o1.backward(go.to(dtype).to(dev()))
+            assert relerr(o1.float().cpu(), o_ref) < tol, fmode
+            assert relerr(qd1.grad.float().cpu(), qkv.grad) < tol, fmode
+            if S:
+                assert relerr(kd1.grad.float().cpu(), kvc.grad) < tol, fmode
+        _lib.lib().mdm_dev_set_attn_fwd(0)
         # ... and every other backward path on the same case (mdm_hip_dev.h: 1 = the two streaming kernels on 16x16x32
         # MFMAs, 3 = one block per head on 16x16x32, 4 = the streaming kernels on 32x32x16 of csrc/attn32.hpp where the
         # shape allows): all must agree with the reference

@@ -79,6 +79,17 @@ def case(B, L, S, H, d, masked, seed=6):
     go = torch.randn(o_ref.shape, generator=g).bfloat16().float()
     o_ref.backward(go)
     ok = True
+    for fmode, fname in ((1, "fwd16"), (2, "fwd32")):      # both forward kernels (mdm_dev_set_attn_fwd)
+        _lib.lib().mdm_dev_set_attn_fwd(fmode)
+        qd = qkv.detach().bfloat16().to(dev)
+        kd = kvc.detach().bfloat16().to(dev) if S else None
+        o = ops.attention(qd, kd, mask.to(dev) if mask is not None else None, H).float().cpu()
+        e = relerr(o, o_ref.detach())
+        print("B=%d L=%d S=%d H=%d d=%d masked=%d  %-8s out %.4f  %s" % (B, L, S, H, d, masked, fname, e, "ok" if e < 3e-2 else "FAIL"), flush=True)
+        if not e < 3e-2:
+            ok = False
+            block_map("out", o, o_ref.detach(), H, d, L)
+    _lib.lib().mdm_dev_set_attn_fwd(0)
     for mode, name in MODES.items():
         _lib.lib().mdm_dev_set_attn_bwd(mode)
         qd = qkv.detach().bfloat16().to(dev).requires_grad_()
@@ -124,8 +135,13 @@ def timing(B=64):
         qkv = torch.randn(B, L, 3 * C, device=dev).bfloat16().requires_grad_()
         kvc = torch.randn(B, 32, 2 * C, device=dev).bfloat16().requires_grad_()
         fl = 4.0 * B * 8 * L * (L + 32) * d
-        tf = timeit(lambda: ops.attention(qkv.detach(), kvc.detach(), None, 8))
-        line = "attn B=%d L=%d d=%d  fwd %.3f ms %.0f TF |" % (B, L, d, tf, fl / tf / 1e9)
+        line = "attn B=%d L=%d d=%d " % (B, L, d)
+        for fmode, fname in ((1, "fwd16"), (2, "fwd32")):
+            _lib.lib().mdm_dev_set_attn_fwd(fmode)
+            tf = timeit(lambda: ops.attention(qkv.detach(), kvc.detach(), None, 8))
+            line += " %s %.3f ms %.0f TF" % (fname, tf, fl / tf / 1e9)
+        _lib.lib().mdm_dev_set_attn_fwd(0)
+        line += " |"
         for mode, name in MODES.items():
             _lib.lib().mdm_dev_set_attn_bwd(mode)
             o = ops.attention(qkv, kvc, None, 8)

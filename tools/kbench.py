@@ -231,6 +231,16 @@ def main():
                 _lib.check(_lib.lib().mdm_gn_bwd(ops._p(gy), ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(stats), ops._p(coef), ops._p(dres), None, ops._p(dxx), ops._p(dg), ops._p(db), None, ops._p(ws), B, H * H, C, 32, 1, gmode, ops._dt(xd), ops._stream()), "bwd")
             def directf():
                 _lib.check(_lib.lib().mdm_gn_fwd(ops._p(xd), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(yy), ops._p(stats), ops._p(coef), ops._p(ws), B, H * H, C, 32, 1e-5, 1, ops._dt(xd), ops._stream()), "fwd")
+            nrot = int(os.environ.get('KB_GN_COLD', '0'))   # > 0: rotate through this many sets of tensors (cold HBM, not the 256 MB MALL)
+            if nrot:
+                sets = [(torch.randn_like(xd), torch.randn_like(xd), torch.empty_like(xd), torch.randn_like(xd) if dres is not None else None, torch.empty_like(xd)) for _ in range(nrot)]
+                L_ = _lib.lib()
+                def direct(i=[0]):
+                    x_, gy_, dx_, dr_, y_ = sets[i[0] % nrot]; i[0] += 1
+                    _lib.check(L_.mdm_gn_bwd(ops._p(gy_), ops._p(x_), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(stats), ops._p(coef), ops._p(dr_), None, ops._p(dx_), ops._p(dg), ops._p(db), None, ops._p(ws), B, H * H, C, 32, 1, gmode, ops._dt(xd), ops._stream()), "bwd")
+                def directf(i=[0]):
+                    x_, gy_, dx_, dr_, y_ = sets[i[0] % nrot]; i[0] += 1
+                    _lib.check(L_.mdm_gn_fwd(ops._p(x_), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(y_), ops._p(stats), ops._p(coef), ops._p(ws), B, H * H, C, 32, 1e-5, 1, ops._dt(xd), ops._stream()), "fwd")
             for f in (direct, directf):
                 for _ in range(3): f()
             e0, e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -241,7 +251,9 @@ def main():
             e2.record()
             torch.cuda.synchronize()
             tb, t = e0.elapsed_time(e1) / 50e3, e1.elapsed_time(e2) / 50e3
-            print("gn %dx%d C=%-5d (%6.1f MB)  fwd %7.3f ms %6.0f GB/s   bwd %7.3f ms %6.0f GB/s" % (H, H, C, nb / 1e6, t * 1e3, 2 * nb / t / 1e9, tb * 1e3, (4 if dres is not None else 3) * nb / tb / 1e9), flush=True)
+            print("gn %dx%d C=%-5d (%6.1f MB)  fwd %7.3f ms %6.0f GB/s   bwd %7.3f ms %6.0f GB/s%s" % (H, H, C, nb / 1e6, t * 1e3, 2 * nb / t / 1e9, tb * 1e3, (4 if dres is not None else 3) * nb / tb / 1e9, "   (cold: %d buffer sets)" % nrot if nrot else ""), flush=True)
+            if nrot:
+                del sets
     if what in ("attn", "all"):
         for L, d in ((1024, 64), (256, 96)):
             C = 8 * d
