@@ -32,6 +32,10 @@ int mdm_dev_set_knob(int idx, int value);
  * one-block-per-head kernel whenever the shape allows (tests), 3 = as 2 but the 16x16x32 one, 4 = the streaming kernels on
  * 32x32x16 MFMAs (csrc/attn32.hpp) whenever the shape allows */
 int mdm_dev_set_attn_bwd(int mode);
+/* GroupNorm backward, two-kernel path (images too large for the register-resident kernel): bytes of x + dy, in MiB,
+ * above which the batch is walked in chunks of samples so that the second kernel's reads still find them in the Infinity
+ * Cache (default 160; 0 = chunk whenever the batch allows it -- the tests; negative = never) */
+int mdm_dev_set_gn_chunk_mb(int mb);
 /* attention forward kernel choice: 0 = by shape, 1 = always the 16x16x32-MFMA kernel, 2 = the 32x32x16 kernel of
  * csrc/attn32.hpp whenever the shape allows (bf16, d = 64 / 96, at most 32 text keys) */
 int mdm_dev_set_attn_fwd(int mode);

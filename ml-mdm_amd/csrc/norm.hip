@@ -864,6 +864,13 @@ __global__ __launch_bounds__(256) void ln_multi_param_kernel(LnGroup g, const T*
 
 using namespace mdm;
 
+// bytes of x + dy above which the two-kernel backward walks the batch in chunks (mdm_dev_set_gn_chunk_mb; 0 = always chunk)
+static size_t g_gn_chunk_bytes = (size_t)160 << 20;
+extern "C" int mdm_dev_set_gn_chunk_mb(int mb) {
+  g_gn_chunk_bytes = mb < 0 ? ~(size_t)0 : (size_t)mb << 20;
+  return 0;
+}
+
 // pixel slabs of the partial-sum stage: about 1024 blocks in total, at least 64 pixels each, at most 256 per sample
 // (round 2 capped them at 32 because every apply block walked the slabs of a channel serially -- 256 slabs at batch 4 made
 // a 64 x 64 norm take 71 us; with gn_slab_sums the walk is 256 / CB-way parallel and four loads deep, and the cap that
@@ -989,19 +996,36 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
 #undef MDM_GN_FUSED_BWD_L
     MDM_LAUNCH_STATUS();
   }
-  const int slabs = gn_slabs(N, HW);
-  const int pps = (HW + slabs - 1) / slabs;
   const int cb = gn_slice(C, G, epv);
   MDM_CHECK_ARG(cb > 0);
-  const int sp = gn_pix_splits(N, HW, C / cb);
+  // Two kernels read x and dy: the partial sums, then the apply.  When the pair is larger than the Infinity Cache keeps
+  // (256 MB on MI355X; 268 MB at 64 x 64 x 256 channels, batch 64) the second read comes from HBM again, so the batch is
+  // walked in chunks of samples whose x + dy fit: partial(chunk), apply(chunk), next chunk.
+  const size_t esize = dtype == DT_F32 ? 4 : 2;
+  int nchunk = 1;
+  while (nchunk < 8 && N % (nchunk * 2) == 0 && N / (nchunk * 2) >= 4 &&
+         2 * (size_t)N * HW * C * esize / nchunk > g_gn_chunk_bytes)
+    nchunk *= 2;
+  if ((size_t)(N / nchunk) * gn_slabs(N / nchunk, HW) > (size_t)N * gn_slabs(N, HW)) nchunk = 1;   // the workspace is sized for N
+  const int nc = N / nchunk;
+  const int slabs = gn_slabs(nc, HW);
+  const int pps = (HW + slabs - 1) / slabs;
+  const int sp = gn_pix_splits(nc, HW, C / cb);
   const int ppb = (HW + sp - 1) / sp;
-  const dim3 agrid(sp, C / cb, N);
+  const dim3 agrid(sp, C / cb, nc);
 #define MDM_GN_BWD(TT, ACT)                                                                                          \
-  hipLaunchKernelGGL((gn_bwd_partial_kernel<TT, ACT>), dim3(N * slabs), dim3(256), 0, st, (const TT*)dy,             \
-                     (const TT*)x, coef, ws, HW, C, slabs, pps);                                                     \
-  hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, ACT>), agrid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, ws, stats, \
-                     coef, gamma, beta, (const TT*)film, (const TT*)dres, (const TT*)dres2, (TT*)dx, (TT*)dfilm, dgamma, dbeta, HW, C, G,  \
-                     cb, slabs, ppb, pstride);
+  for (int ch = 0; ch < nchunk; ++ch) {                                                                              \
+    const size_t n0 = (size_t)ch * nc, t0 = n0 * HW * C;                                                             \
+    const TT* film_ = film ? (const TT*)film + n0 * 2 * C : nullptr;                                                 \
+    TT* dfilm_ = dfilm ? (TT*)dfilm + n0 * 2 * C : nullptr;                                                          \
+    const TT* dres_ = dres ? (const TT*)dres + t0 : nullptr;                                                         \
+    const TT* dres2_ = dres2 ? (const TT*)dres2 + t0 : nullptr;                                                      \
+    hipLaunchKernelGGL((gn_bwd_partial_kernel<TT, ACT>), dim3(nc * slabs), dim3(256), 0, st, (const TT*)dy + t0,     \
+                       (const TT*)x + t0, coef + n0 * C * 2, ws, HW, C, slabs, pps);                                 \
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, ACT>), agrid, dim3(256), 0, st, (const TT*)dy + t0, (const TT*)x + t0, ws, \
+                       stats + n0 * G * 2, coef + n0 * C * 2, gamma, beta, film_, dres_, dres2_, (TT*)dx + t0, dfilm_, \
+                       dgamma + n0 * pstride, dbeta + n0 * pstride, HW, C, G, cb, slabs, ppb, pstride);              \
+  }
   if (dtype == DT_F32) { if (act) { MDM_GN_BWD(float, 1) } else { MDM_GN_BWD(float, 0) } }
   else { if (act) { MDM_GN_BWD(bf16, 1) } else { MDM_GN_BWD(bf16, 0) } }
 #undef MDM_GN_BWD

@@ -173,6 +173,8 @@ def _apply_dev_env(handle):
         handle.mdm_dev_set_attn_fwd({"fwd16": 1, "fwd32": 2}.get(os.environ["MDM_HIP_ATTN_FWD"], 0))
     if os.environ.get("MDM_HIP_SKIP_WGRAD_REDUCE") == "1":      # timing-only ablation, wrong gradients
         handle.mdm_dev_set_knob(13, 1)
+    if os.environ.get("MDM_HIP_GN_CHUNK_MB"):
+        handle.mdm_dev_set_gn_chunk_mb(int(os.environ["MDM_HIP_GN_CHUNK_MB"]))
     if os.environ.get("MDM_HIP_SPLIT_FILL"):
         handle.mdm_dev_set_knob(6, int(os.environ["MDM_HIP_SPLIT_FILL"]))
     if os.environ.get("MDM_HIP_CONV_DIRECT") == "0":

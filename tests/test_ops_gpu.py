@@ -840,6 +840,50 @@ def test_fails_loudly_without_gpu_tensor():
         ops.silu(torch.randn(4, 8))
 
 
+@pytest.mark.parametrize("deferred", [False, True])
+def test_group_norm_backward_in_sample_chunks(deferred, request):
+    """two-kernel GroupNorm backward walking the batch in chunks of samples (mdm_dev_set_gn_chunk_mb: the second kernel's
+    reads of x and dy then come out of the Infinity Cache) == the whole batch at once; atomic and per-sample-row
+    parameter gradients, FiLM gradients, residual-branch gradient"""
+    from mdm_hip import _lib, ops
+
+    class Sink:
+        def __init__(self, params):
+            self.slots = {p.data_ptr(): torch.zeros_like(p) for p in params}
+
+        def slot(self, p):
+            return self.slots.get(p.data_ptr())
+
+        def ready(self, p):
+            pass
+
+    request.addfinalizer(lambda: (_lib.lib().mdm_dev_set_gn_chunk_mb(160), ops.set_grad_sink(None), ops.enable_deferred_wgrad(False)))
+    g = torch.Generator().manual_seed(9)
+    N, H, C = 16, 8, 192          # 6 channels per group: not register-resident -> partial + apply kernels
+    gam = (1 + 0.1 * torch.randn(C, generator=g)).to(dev()).requires_grad_()
+    bet = (0.1 * torch.randn(C, generator=g)).to(dev()).requires_grad_()
+    x0 = torch.randn(N, H, H, C, generator=g).to(dev()).to(torch.bfloat16)
+    fl = (0.2 * torch.randn(N, 2 * C, generator=g)).to(dev()).to(torch.bfloat16)
+    res = []
+    for mb in (-1, 0):            # never chunk / chunk whenever the batch allows it (4 chunks of 4 samples)
+        _lib.lib().mdm_dev_set_gn_chunk_mb(mb)
+        sink = Sink([gam, bet]) if deferred else None
+        ops.set_grad_sink(sink)
+        ops.enable_deferred_wgrad(deferred)
+        gam.grad = bet.grad = None
+        x = x0.clone().requires_grad_()
+        f = fl.clone().requires_grad_()
+        h = x + ops.group_norm(x, gam, bet, 32, film=f, silu=True)     # the residual gradient joins inside the backward
+        (h.float() * torch.linspace(-1, 1, C, device=dev())).square().mean().backward()
+        ops.flush_wgrad_queue()
+        torch.cuda.synchronize()
+        pg = [sink.slots[p.data_ptr()].clone() for p in (gam, bet)] if deferred else [gam.grad.clone(), bet.grad.clone()]
+        res.append((x.grad.float().clone(), f.grad.float().clone(), pg))
+    assert relerr(res[1][0], res[0][0]) < 2e-3 and relerr(res[1][1], res[0][1]) < 2e-3
+    for a_, b_ in zip(res[0][2], res[1][2]):
+        assert float(a_.abs().max()) > 0 and relerr(b_, a_) < 1e-4
+
+
 @pytest.mark.parametrize("H,C,film", [(16, 768, False), (16, 1536, True), (32, 512, True), (64, 256, False)])
 def test_deferred_group_norm_param_grads_equal_atomic_path(H, C, film):
     """with the gradient sink + deferral the GroupNorm backward stores per-sample rows and ONE multi-layer reduce adds
