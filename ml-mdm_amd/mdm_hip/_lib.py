@@ -36,6 +36,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     deps = srcs + [HEADER] + hdrs
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+            _write_build_note(deps, refresh=True)
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
@@ -65,9 +66,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB_PATH
 
 
-def _write_build_note(deps):
+def _write_build_note(deps, refresh=False):
     """<lib>.build.json next to the library: what it was built from (git revision + a hash of every source it depends on).
-    The .so is git-ignored but ships to the GPU box, where there is no .git: provenance() reads this note there."""
+    The .so is git-ignored but ships to the GPU box, where there is no .git: provenance() reads this note there.
+    ``refresh``: the library is up to date -- only the revision is renewed, and only where there IS a repository and the
+    sources still hash to what the note says (a library built from a dirty tree that was committed afterwards)."""
     import hashlib
     import json
     h = hashlib.sha256()
@@ -80,8 +83,18 @@ def _write_build_note(deps):
         except OSError:
             return ""
     note = {"git_describe": git("describe", "--always", "--dirty", "--abbrev=12"), "sources_sha256": h.hexdigest()}
-    with open(LIB_PATH + ".build.json", "w") as f:
-        json.dump(note, f)
+    if refresh:
+        try:
+            old = json.load(open(LIB_PATH + ".build.json"))
+        except (OSError, ValueError):
+            return
+        if not note["git_describe"] or old.get("sources_sha256") != note["sources_sha256"] or old.get("git_describe") == note["git_describe"]:
+            return
+    try:
+        with open(LIB_PATH + ".build.json", "w") as f:
+            json.dump(note, f)
+    except OSError:
+        pass
 
 
 def provenance():

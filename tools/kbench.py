@@ -235,9 +235,14 @@ def main():
             if nrot:
                 sets = [(torch.randn_like(xd), torch.randn_like(xd), torch.empty_like(xd), torch.randn_like(xd) if dres is not None else None, torch.empty_like(xd)) for _ in range(nrot)]
                 L_ = _lib.lib()
+                # KB_GN_FULL=1: as the ResNet's second norm runs it -- FiLM (+ its gradient) and a second residual-branch gradient
+                full = os.environ.get('KB_GN_FULL') == '1'
+                flm = (0.1 * torch.randn(B, 2 * C, device=dev)).to(DT) if full else None
+                dflm = torch.empty_like(flm) if full else None
+                dr2 = torch.randn_like(xd) if full else None
                 def direct(i=[0]):
                     x_, gy_, dx_, dr_, y_ = sets[i[0] % nrot]; i[0] += 1
-                    _lib.check(L_.mdm_gn_bwd(ops._p(gy_), ops._p(x_), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(stats), ops._p(coef), ops._p(dr_), None, ops._p(dx_), ops._p(dg), ops._p(db), None, ops._p(ws), B, H * H, C, 32, 1, gmode, ops._dt(xd), ops._stream()), "bwd")
+                    _lib.check(L_.mdm_gn_bwd(ops._p(gy_), ops._p(x_), ops._p(gam.detach()), ops._p(bet.detach()), ops._p(flm), ops._p(stats), ops._p(coef), ops._p(dr_), ops._p(dr2), ops._p(dx_), ops._p(dg), ops._p(db), ops._p(dflm), ops._p(ws), B, H * H, C, 32, 1, gmode, ops._dt(xd), ops._stream()), "bwd")
                 def directf(i=[0]):
                     x_, gy_, dx_, dr_, y_ = sets[i[0] % nrot]; i[0] += 1
                     _lib.check(L_.mdm_gn_fwd(ops._p(x_), ops._p(gam.detach()), ops._p(bet.detach()), None, ops._p(y_), ops._p(stats), ops._p(coef), ops._p(ws), B, H * H, C, 32, 1e-5, 1, ops._dt(xd), ops._stream()), "fwd")
