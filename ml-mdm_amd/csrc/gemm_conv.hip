@@ -1589,6 +1589,13 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #undef MDM_WG_PIECE_RT
 #undef MDM_WG_ITER
+  } else if (bias_blk && p.groups == 0 && quad == 0) {
+    // a split without reduction tiles (the host's split counts do not produce one): its rows of partial sums are zeros
+#pragma unroll
+    for (int r = 0; r < BR; ++r) {
+      const int n = n0 + wm * TM + (wn * BR + r) * 16 + l16;
+      if (n < p.Cout) p.bslab[((size_t)split * bias_share + kt_rel) * p.Cout + n] = 0.f;
+    }
   }
 #undef MDM_WG_PIECE
 #undef MDM_WG_TILE_STATE
