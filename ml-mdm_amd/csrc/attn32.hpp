@@ -1,4 +1,6 @@
-// Attention backward on v_mfma_f32_32x32x16_bf16 (included by attention.hip; reference ml_mdm/models/unet.py:276-313).
+// Attention on v_mfma_f32_32x32x16_bf16 (included by attention.hip; reference ml_mdm/models/unet.py:276-313): the backward
+// kernels of the product path, and a forward on the same tiles that is NOT faster than attn_fwd_kernel and sits behind a
+// development switch (see the comment in front of f_step64).
 //
 // Why another set of kernels.  The 16x16x32 kernels of attention.hip give a wave 16 keys (or queries): at the 16x16 level
 // of the U-Net (L = 256, d = 96; 26 of 31 attention layers) the one-block-per-head backward walks the query tiles TWICE

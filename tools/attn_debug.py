@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Development aid for the attention backward kernels: every backward path (mdm_dev_set_attn_bwd 1 = split, 2 = small
+"""Development aid for the attention kernels: both forward kernels (mdm_dev_set_attn_fwd 1 = 16x16x32, 2 = 32x32x16) and
+every backward path (mdm_dev_set_attn_bwd 1 = split, 2 = small
 (32x32 MFMA where the shape allows), 3 = small16) against a torch fp32 reference on the same bf16 inputs, error per output
 tensor, and -- when one is off -- a map of the worst 32 x 32 blocks of the first failing (batch, head).
    gpurun -- python tools/attn_debug.py            # correctness cases
