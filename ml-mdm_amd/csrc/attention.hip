@@ -1245,11 +1245,15 @@ template <typename T, int D, bool SPLIT = false>
 static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   using G = AttnGeom<T, D>;
   if constexpr (sizeof(T) == 2 && !SPLIT && (D == 64 || D == 96)) {
-    // a wave owns 32 queries on 32x32x16 MFMAs (half the LDS bytes per FLOP): bf16, at most one tile of text keys, and
-    // enough (batch, head, 128-query) blocks for the chip -- the small-batch sampler keeps the 16-queries-per-wave form below
+    // a wave owns 32 queries on 32x32x16 MFMAs (attn_fwd32_kernel): bf16, at most one tile of text keys.  By shape it is
+    // taken where it measured faster -- d = 96 at L <= 256 with enough (batch, head, 128-query) blocks for the chip: 44-46
+    // against 47-49 us per layer of the 16x16 level; at d = 64 it is equal (L = 256) or 6-9 % slower (L = 1024): the loop is
+    // VALU-bound in either tiling (profiles/r05_did_not_pay.md #18).  The small-batch sampler keeps the 16-queries-per-wave
+    // form below.
     const long blocks = (long)((a.L + 127) / 128) * a.B * a.H;
     const bool can = !a.kc || (a.S <= 32 && a.out_cross);   // the cross part is staged through out_cross
-    if (can && g_attn_fwd_mode != 1 && (g_attn_fwd_mode == 2 || blocks >= device_cus())) {
+    const bool pays = D == 96 && a.L <= 256 && blocks >= device_cus();
+    if (can && g_attn_fwd_mode != 1 && (g_attn_fwd_mode == 2 || pays)) {
       ensure_dynamic_lds(attn_fwd32_kernel<D>, attn_fwd32_lds<D>());
       hipLaunchKernelGGL(attn_fwd32_kernel<D>, dim3((a.L + 127) / 128, a.B * a.H), dim3(256), attn_fwd32_lds<D>(), st, a);
       MDM_LAUNCH_STATUS();
