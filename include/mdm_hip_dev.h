@@ -36,9 +36,8 @@ int mdm_dev_set_attn_bwd(int mode);
  * above which the batch is walked in chunks of samples so that the second kernel's reads still find them in the Infinity
  * Cache (default 160; 0 = chunk whenever the batch allows it -- the tests; negative = never) */
 int mdm_dev_set_gn_chunk_mb(int mb);
-/* attention forward kernel choice: 0 = by shape (the 32x32x16 kernel of csrc/attn32.hpp for d = 96 at L <= 256, where it
- * measured faster), 1 = always the 16x16x32-MFMA kernel, 2 = the 32x32x16 kernel whenever the shape allows (bf16,
- * d = 64 / 96, at most 32 text keys) */
+/* attention forward kernel choice: 0 / 1 = the 16x16x32-MFMA kernel (the product path), 2 = the 32x32x16 kernel of
+ * csrc/attn32.hpp whenever the shape allows (bf16, d = 64 / 96, at most 32 text keys; no gain in the train step) */
 int mdm_dev_set_attn_fwd(int mode);
 /* phase time stamps of attn_bwd_small32_kernel: a device buffer of [blocks][8][16] 64-bit words (tools/attn_debug.py), or
  * null (the default) */

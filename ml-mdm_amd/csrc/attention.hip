@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
 
 using namespace mdm;
 
-// development knob (mdm_hip_dev.h): forward kernel choice, 0 = by shape, 1 = always attn_fwd_kernel (16x16x32 MFMAs),
+// development knob (mdm_hip_dev.h): forward kernel choice, 0 / 1 = attn_fwd_kernel (16x16x32 MFMAs; the product path),
 // 2 = attn_fwd32_kernel (csrc/attn32.hpp) whenever it can express the problem
 static int g_attn_fwd_mode = 0;
 extern "C" int mdm_dev_set_attn_fwd(int mode) {
@@ -1245,15 +1245,13 @@ template <typename T, int D, bool SPLIT = false>
 static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   using G = AttnGeom<T, D>;
   if constexpr (sizeof(T) == 2 && !SPLIT && (D == 64 || D == 96)) {
-    // a wave owns 32 queries on 32x32x16 MFMAs (attn_fwd32_kernel): bf16, at most one tile of text keys.  By shape it is
-    // taken where it measured faster -- d = 96 at L <= 256 with enough (batch, head, 128-query) blocks for the chip: 44-46
-    // against 47-49 us per layer of the 16x16 level; at d = 64 it is equal (L = 256) or 6-9 % slower (L = 1024): the loop is
-    // VALU-bound in either tiling (profiles/r05_did_not_pay.md #18).  The small-batch sampler keeps the 16-queries-per-wave
-    // form below.
-    const long blocks = (long)((a.L + 127) / 128) * a.B * a.H;
+    // a wave owns 32 queries on 32x32x16 MFMAs (attn_fwd32_kernel): bf16, at most one tile of text keys.  Only on request
+    // (mode 2): standalone it is 6 % faster at d = 96 / L = 256 (44-46 against 47-49 us), equal at d = 64 / L = 256 and
+    // 6-9 % slower at L = 1024, and inside the train step neither "everywhere" (90.80 / 90.71 ms) nor "d = 96 only"
+    // (90.62 / 90.60) beats attn_fwd_kernel (90.36 / 90.58, alternated in one call) -- the loop is VALU-bound in either
+    // tiling (profiles/r05_did_not_pay.md #18).
     const bool can = !a.kc || (a.S <= 32 && a.out_cross);   // the cross part is staged through out_cross
-    const bool pays = D == 96 && a.L <= 256 && blocks >= device_cus();
-    if (can && g_attn_fwd_mode != 1 && (g_attn_fwd_mode == 2 || pays)) {
+    if (can && g_attn_fwd_mode == 2) {
       ensure_dynamic_lds(attn_fwd32_kernel<D>, attn_fwd32_lds<D>());
       hipLaunchKernelGGL(attn_fwd32_kernel<D>, dim3((a.L + 127) / 128, a.B * a.H), dim3(256), attn_fwd32_lds<D>(), st, a);
       MDM_LAUNCH_STATUS();

@@ -1,6 +1,6 @@
 // Attention on v_mfma_f32_32x32x16_bf16 (included by attention.hip; reference ml_mdm/models/unet.py:276-313): the backward
-// kernels of the product path, and a forward on the same tiles that is 6 % faster than attn_fwd_kernel at d = 96 / L = 256
-// (taken there) and slower at L = 1024 (see the comment in front of f_step64 and attention.hip's attn_fwd_launch).
+// kernels of the product path, and a forward on the same tiles that does not beat attn_fwd_kernel in the train step and sits
+// behind a development switch (see the comment in front of f_step64 and attention.hip's attn_fwd_launch).
 //
 // Why another set of kernels.  The 16x16x32 kernels of attention.hip give a wave 16 keys (or queries): at the 16x16 level
 // of the U-Net (L = 256, d = 96; 26 of 31 attention layers) the one-block-per-head backward walks the query tiles TWICE
