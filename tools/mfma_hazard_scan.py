@@ -5,7 +5,10 @@ recognizer covered the fall-through path only (conv3x3_direct_kernel<64, 64, 8, 
 Walks every path of up to 10 wait states after each v_mfma (following branches) and reports reads of its destination
 registers that come earlier than `MIN_WS` (the compiler itself leaves 11 in straight-line code).  CPU-only:
    python tools/mfma_hazard_scan.py            # compiles csrc/gemm_conv.hip and attention.hip to ISA, exits 1 on a finding
-Also checks, on the same ISA, that no kernel spills more than SPILL_CAP vector registers."""
+Also checks, on the same ISA, that no kernel spills more than SPILL_CAP vector registers, and that the bias-gradient dot
+products of conv_wgrad_bl_kernel still sit behind scalar branches (round 5: as plain code hipcc if-converted them into every
+wave's instruction stream -- all 64 v_dot2c + a v_cndmask per row -- which is what made one block in nine the tail of the
+launch; a parity test does not see that either)."""
 import collections
 import os
 import re
@@ -73,6 +76,32 @@ def analyze(path):
     return findings
 
 
+def unguarded_dot2(path):
+    """v_dot2c instructions of conv_wgrad_bl_kernel that are reached from an MFMA without a conditional branch in between
+    (the guarded form is: MFMAs, s_cbranch around a block of four v_dot2c, label)"""
+    txt = open(path).read()
+    out = []
+    for km in re.finditer(r"^(\S*conv_wgrad_bl_kernel\S*):\s*; @\1\n", txt, re.M):
+        name, i = km.group(1), km.end()
+        lines = [ln.strip() for ln in txt[i:txt.find(".Lfunc_end", i)].split("\n")]
+        code = [ln for ln in lines if ln and not ln.startswith(";") and not ln.startswith(".")]
+        n_dot = 0
+        for k, ln in enumerate(code):
+            if not ln.startswith("v_dot2c"):
+                continue
+            n_dot += 1
+            j = k - 1
+            while j >= 0 and code[j].startswith("v_dot2c"):
+                j -= 1
+            while j >= 0 and not (code[j].startswith("s_cbranch") or code[j].startswith("v_mfma")):
+                j -= 1
+            if j < 0 or code[j].startswith("v_mfma"):
+                out.append((name, ln))
+        if n_dot == 0:
+            out.append((name, "no v_dot2c at all: the bias sums moved -- update this check"))
+    return out
+
+
 def main():
     srcs = sys.argv[1:] or ["gemm_conv.hip", "attention.hip"]
     bad = 0
@@ -99,6 +128,12 @@ def main():
             for n, k in over:
                 print("   OVER THE SPILL CAP (%d): %d %s" % (SPILL_CAP, n, k))
             bad += len(over)
+            if os.path.basename(src) == "gemm_conv.hip":
+                ung = unguarded_dot2(out)
+                print("   conv_wgrad_bl_kernel: %d bias-sum dot products not behind a scalar branch" % len(ung))
+                for name, ln in ung[:4]:
+                    print("      %s: %s" % (name[:60], ln))
+                bad += len(ung)
     return 1 if bad else 0
 
 
