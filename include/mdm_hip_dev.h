@@ -15,11 +15,10 @@ int mdm_conv_wgrad_tile(int M, int Cout, int K, int dtype);
 
 /* development knobs of the GEMM kernels (all 0 / default in the product; host-side state of the calling process, never
  * read from the environment inside an entry point).  Experiments recorded in DESIGN.md / profiles/.
- *   0  conv_gemm_x_kernel: bit 0 = its LDS-DMA fetches nothing, bit 1 = its barriers do not wait for the DMA (timing only)
+ *   0  conv_gemm_bl_kernel: bit 0 = its LDS-DMA fetches nothing (timing only: what the k-loop costs without memory)
  *   1  epilogues skip their global stores (what the store phase costs)
  *   2  force the forward tile of conv_gemm_bl_kernel (128128 / 256192 / 256256)
- *   3  conv_gemm_x_kernel (csrc/gemm_x.hpp): 0 / 1 = never (the product: it does not pay inside the train step), 2 = whenever the problem allows
- *   4  conv_gemm_x_kernel tile order: 0 = row-major, 1 = super-tiles (default)
+ *   3, 4  unused (were the switches of conv_gemm_x_kernel, removed in round 6: profiles/r04_gemm_x8_probe.txt is its record)
  *   6  tile-fill percentage below which a forward GEMM may split its reduction (default 80; 25 = the sampling-only rule)
  *   7  1 = the narrow 3x3 convolutions of the nested models go back to the implicit-GEMM kernel (no conv3x3_direct_kernel)
  *   8  1 = the narrow weight gradients (64 output channels, >= 262144 pixels) go back to the split GEMM (no wgrad_direct_kernel)
@@ -36,9 +35,6 @@ int mdm_dev_set_attn_bwd(int mode);
  * above which the batch is walked in chunks of samples so that the second kernel's reads still find them in the Infinity
  * Cache (default 160; 0 = chunk whenever the batch allows it -- the tests; negative = never) */
 int mdm_dev_set_gn_chunk_mb(int mb);
-/* attention forward kernel choice: 0 / 1 = the 16x16x32-MFMA kernel (the product path), 2 = the 32x32x16 kernel of
- * csrc/attn32.hpp whenever the shape allows (bf16, d = 64 / 96, at most 32 text keys; no gain in the train step) */
-int mdm_dev_set_attn_fwd(int mode);
 /* phase time stamps of attn_bwd_small32_kernel: a device buffer of [blocks][8][16] 64-bit words (tools/attn_debug.py), or
  * null (the default) */
 int mdm_dev_set_attn_dbg(void* buf);

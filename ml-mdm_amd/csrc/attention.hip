@@ -1232,31 +1232,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_small_kernel(AttnArgs p) {
 
 using namespace mdm;
 
-// development knob (mdm_hip_dev.h): forward kernel choice, 0 / 1 = attn_fwd_kernel (16x16x32 MFMAs; the product path),
-// 2 = attn_fwd32_kernel (csrc/attn32.hpp) whenever it can express the problem
-static int g_attn_fwd_mode = 0;
-extern "C" int mdm_dev_set_attn_fwd(int mode) {
-  if (mode < 0 || mode > 2) return -1;
-  g_attn_fwd_mode = mode;
-  return 0;
-}
-
 template <typename T, int D, bool SPLIT = false>
 static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   using G = AttnGeom<T, D>;
-  if constexpr (sizeof(T) == 2 && !SPLIT && (D == 64 || D == 96)) {
-    // a wave owns 32 queries on 32x32x16 MFMAs (attn_fwd32_kernel): bf16, at most one tile of text keys.  Only on request
-    // (mode 2): standalone it is 6 % faster at d = 96 / L = 256 (44-46 against 47-49 us), equal at d = 64 / L = 256 and
-    // 6-9 % slower at L = 1024, and inside the train step neither "everywhere" (90.80 / 90.71 ms) nor "d = 96 only"
-    // (90.62 / 90.60) beats attn_fwd_kernel (90.36 / 90.58, alternated in one call) -- the loop is VALU-bound in either
-    // tiling (profiles/r05_did_not_pay.md #18).
-    const bool can = !a.kc || (a.S <= 32 && a.out_cross);   // the cross part is staged through out_cross
-    if (can && g_attn_fwd_mode == 2) {
-      ensure_dynamic_lds(attn_fwd32_kernel<D>, attn_fwd32_lds<D>());
-      hipLaunchKernelGGL(attn_fwd32_kernel<D>, dim3((a.L + 127) / 128, a.B * a.H), dim3(256), attn_fwd32_lds<D>(), st, a);
-      MDM_LAUNCH_STATUS();
-    }
-  }
   constexpr int smem = sizeof(T) == 2 ? 4 * G::NAT_BYTES : G::NAT_BYTES + (G::NAT_BYTES > G::TR_BYTES ? G::NAT_BYTES : G::TR_BYTES);
   ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, true, SPLIT>, smem);
   ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, false, SPLIT>, smem);

@@ -991,252 +991,6 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv32_kernel(AttnArgs p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Forward on the same tiles (reference ml_mdm/models/unet.py:276-313): out = softmax(Q K^T) V + softmax_masked(Q K_c^T) V_c.
-//   block = 4 waves x 32 queries (two blocks per CU: one's prologue / stores lie under the other's tiles); K and V stream
-//   through LDS in stages of 64 keys exactly as in attn_bwd_dq32_kernel (three stages, fetch two ahead), the text keys are
-//   stage 0 -- their softmax is finished (normalised, written to out_cross / lse_cross for the backward) before the self
-//   keys start, so one accumulator set serves both; the final store reads the cross part back (same lane, L2-warm), as
-//   attn_fwd_kernel's OCM form does: 16 NB registers less across the self loop.
-//   One step = one stage = two 32-key tiles (lane <-> query, 16 of a tile's 32 keys per half-wave):
-//     S^T = K Q^T of both tiles (2 KS MFMAs, K operands read one step ahead)  |  V^T transpose reads of tile a issued  |
-//     maximum over the 64 keys (one v_permlane32_swap joins the two halves of a query), 2^(c2 S - m), row sum  |
-//     O^T += V^T P^T of tile a (KS MFMAs; P's registers 8 s .. 8 s + 7 are the B operand of step s as they are)  |  V^T
-//     reads of tile b, the next stage's K operands  |  O^T += V^T P^T of tile b.
-//   The running maximum is LAZY: it moves (and O^T, l are rescaled -- 16 NB multiplies) only when some query of the wave
-//   sees a tile maximum more than 8 above it, so P <= 2^8 and the usual case is no rescale at all; the result is the same
-//   softmax (l is accumulated against the same m), lse = m ln 2 + ln l.
-// ---------------------------------------------------------------------------------------------------------------------
-// acc += the bf16 row behind row_ptr, in the accumulators' layout (register r of block blk <-> channel 32 blk + 8 (r >> 2) + 4 hi + (r & 3))
-template <int D>
-__device__ __forceinline__ void add_rows32(const bf16* row_ptr, f32x16 (&acc)[A32<D>::NB], const int hi, const bool ok) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-#pragma unroll
-  for (int blk = 0; blk < A32<D>::NB; ++blk)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (!ok) continue;
-      const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(row_ptr + 32 * blk + 8 * g + 4 * hi);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[blk][4 * g + e] += (float)v[e];
-    }
-}
-
-template <int D> struct FPf { static constexpr int value = D <= 64 ? A32<D>::KS : 3; };
-// One stage = two 32-key tiles (a: rows 0-31 of the stage, b: rows 32-63) in ONE step: the two score tiles are independent
-// MFMA chains (a 32x32x16 MFMA has 16 passes of latency; one chain of KS dependent products per step left the matrix pipe
-// idle most of the time with two waves per SIMD), and the maximum / rescale / row-sum bookkeeping is paid once per 64 keys.
-// V^T of tile b is read after tile a's products are issued (registers).
-template <int D>
-__device__ __forceinline__ void f_step64(bf16x8 (&ko)[2][FPf<D>::value], const char* Kt, const char* Vt, const char* Kn,
-                                         const bf16x8 (&qf)[A32<D>::KS], float& m_run, float& l_run, const unsigned live_a,
-                                         const unsigned live_b, const float c2, const int hi, const Frag32Off<D>& fo,
-                                         f32x16 (&o)[A32<D>::NB]) {
-  using G = A32<D>;
-  constexpr int PF = FPf<D>::value, T32 = 32 * G::PITCH;
-  bf16x8 xr[2][G::KS - PF + 1];
-#pragma unroll
-  for (int s = PF; s < G::KS; ++s) {
-    xr[0][s - PF] = lds_b128(Kt + fo.b[s]);
-    xr[1][s - PF] = lds_b128(Kt + T32 + fo.b[s]);
-  }
-  const f32x16 zero = splat16(0.f);
-  f32x16 sa, sb;
-#pragma unroll
-  for (int s = 0; s < PF; ++s) {
-    sa = mma32(ko[0][s], qf[s], s == 0 ? zero : sa);
-    sb = mma32(ko[1][s], qf[s], s == 0 ? zero : sb);
-  }
-#pragma unroll
-  for (int s = PF; s < G::KS; ++s) {
-    sa = mma32(xr[0][s - PF], qf[s], sa);
-    sb = mma32(xr[1][s - PF], qf[s], sb);
-  }
-  MDM_FENCE();
-  bf16x8 tv[2][G::NB];
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-    for (int blk = 0; blk < G::NB; ++blk)
-      tv[s2][blk] = lds_tr_pair(Vt + s2 * 16 * G::PITCH + fo.tr[0][blk], Vt + s2 * 16 * G::PITCH + fo.tr[1][blk]);
-  MDM_FENCE();
-  const bool full = (live_a & live_b) == 0xffffffffu;        // wave-uniform
-  const unsigned la = live_a >> (4 * hi), lb = live_b >> (4 * hi);   // this lane's registers hold keys (r & 3) + 8 (r >> 2) + 4 hi
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int kb = (r & 3) + 8 * (r >> 2);
-    mx = fmaxf(mx, (full || ((la >> kb) & 1u)) ? sa[r] : -3.0e38f);
-    mx = fmaxf(mx, (full || ((lb >> kb) & 1u)) ? sb[r] : -3.0e38f);
-  }
-  {
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-    mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // both halves of the query
-  }
-  const float tm = fmaxf(mx * c2, -1e30f);                   // a stage without a live key leaves the maximum alone
-  if (__any(tm > m_run + 8.f)) {
-    const float m_new = fmaxf(m_run, tm);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    l_run *= alpha;
-#pragma unroll
-    for (int blk = 0; blk < G::NB; ++blk) o[blk] *= alpha;
-  }
-  const float nm = -m_run;
-  if (full) {
-    const f32x2 c2v = {c2, c2}, nmv = {nm, nm};
-    f32x2 l2 = {0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const f32x2 ea = f32x2{sa[r], sa[r + 1]} * c2v + nmv, eb = f32x2{sb[r], sb[r + 1]} * c2v + nmv;
-      const f32x2 pa = {MDM_EXP2(ea[0]), MDM_EXP2(ea[1])}, pb = {MDM_EXP2(eb[0]), MDM_EXP2(eb[1])};
-      l2 += pa + pb;
-      sa[r] = pa[0]; sa[r + 1] = pa[1];
-      sb[r] = pb[0]; sb[r + 1] = pb[1];
-    }
-    l_run += l2[0] + l2[1];
-  } else {
-    float ls = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kb = (r & 3) + 8 * (r >> 2);
-      const float pa = ((la >> kb) & 1u) ? MDM_EXP2(fmaf(sa[r], c2, nm)) : 0.f;
-      const float pb = ((lb >> kb) & 1u) ? MDM_EXP2(fmaf(sb[r], c2, nm)) : 0.f;
-      sa[r] = pa; sb[r] = pb; ls += pa + pb;
-    }
-    l_run += ls;
-  }
-  const bf16x8 pa0 = pack8(sa, 0), pa1 = pack8(sa, 1), pb0 = pack8(sb, 0), pb1 = pack8(sb, 1);
-  MDM_FENCE();
-#pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) o[blk] = mma32(tv[0][blk], pa0, o[blk]);
-#pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) o[blk] = mma32(tv[1][blk], pa1, o[blk]);
-  MDM_FENCE();
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-    for (int blk = 0; blk < G::NB; ++blk)
-      tv[s2][blk] = lds_tr_pair(Vt + T32 + s2 * 16 * G::PITCH + fo.tr[0][blk], Vt + T32 + s2 * 16 * G::PITCH + fo.tr[1][blk]);
-#pragma unroll
-  for (int s = 0; s < PF; ++s) {
-    ko[0][s] = lds_b128(Kn + fo.b[s]);
-    ko[1][s] = lds_b128(Kn + T32 + fo.b[s]);
-  }
-  MDM_FENCE();
-#pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) o[blk] = mma32(tv[0][blk], pb0, o[blk]);
-#pragma unroll
-  for (int blk = 0; blk < G::NB; ++blk) o[blk] = mma32(tv[1][blk], pb1, o[blk]);
-}
-
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
-  using T = bf16;
-  using G = A32<D>;
-  using ST = Stream32<D, 256>;
-  constexpr int KS = G::KS, NB = G::NB, PITCH = G::PITCH, T32 = 32 * PITCH, PF = FPf<D>::value;
-  constexpr int STAGE = 2 * ST::HALF, SR = ST::SR, NSUB = ST::NSUB;   // K rows | V rows of SR keys; three stages in LDS
-  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = lane & 31, hi = lane >> 5;
-  const Frag32Off<D> fo(lane);
-  const int bx_ = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
-  const int by = bx_ / (int)gridDim.x, bx = bx_ - by * (int)gridDim.x;
-  const int b = by / p.H, h = by - b * p.H;
-  const bool has_c = p.kc != nullptr;
-  const int L = p.L, S = has_c ? p.S : 0;
-  const float c2 = p.scale * LOG2E;
-
-  const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * D;
-  const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)b * p.k_bs + (size_t)h * D;
-  const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)b * p.k_bs + (size_t)h * D;
-  const T* Kcp = has_c ? reinterpret_cast<const T*>(p.kc) + (size_t)b * p.c_bs + (size_t)h * D : Kp;
-  const T* Vcp = has_c ? reinterpret_cast<const T*>(p.vc) + (size_t)b * p.c_bs + (size_t)h * D : Vp;
-  const RowSrc qsrc(Qp, p.q_rs, L), ksrc(Kp, p.k_rs, L), vsrc(Vp, p.k_rs, L);
-  const RowSrc kcsrc(Kcp, has_c ? p.c_rs : p.k_rs, S), vcsrc(Vcp, has_c ? p.c_rs : p.k_rs, S);
-  const unsigned tmask = has_c ? text_mask32(p, b, S, lane) : 0u;
-
-  const int q0 = bx * 128 + wave * 32, qi = q0 + n;
-  const bool w_active = __builtin_amdgcn_readfirstlane(q0) < L, qok = qi < L;
-  const int nself = (L + SR - 1) / SR, nc = has_c ? 1 : 0, ntot = nself + nc;
-  // stage t: the text keys (t == 0 when there are any), then self keys SR (t - nc) .. + SR - 1
-  uint4 stg[ST::NVS];
-  auto fetch = [&](const int t) {
-    if (t < nc) ST::fetch(stg, kcsrc, vcsrc, 0, tid);
-    else ST::fetch(stg, ksrc, vsrc, (t - nc) * SR, tid);
-  };
-  fetch(0);
-  bf16x8 qf[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) qf[s] = qsrc.frag(qi, s, hi);
-  ST::commit(smem, stg, tid);
-  if (ntot > 1) {
-    fetch(1);
-    ST::commit(smem + STAGE, stg, tid);
-  }
-  f32x16 o[NB];
-#pragma unroll
-  for (int blk = 0; blk < NB; ++blk) o[blk] = splat16(0.f);
-  T* const ocrow = has_c ? reinterpret_cast<T*>(p.out_cross) + (size_t)b * p.o_bs + (size_t)h * D + (size_t)(qok ? qi : 0) * p.o_rs : nullptr;
-  float m_run = -1e30f, l_run = 0.f;
-  const size_t lo = ((size_t)b * p.H + h) * L + (qok ? qi : 0);
-  frags_arrived(qf);
-  __syncthreads();                                             // stages 0 and 1 are in LDS
-  static_assert(NSUB == 2, "f_step64 takes a stage of two tiles");
-  bf16x8 ko[2][PF];
-#pragma unroll
-  for (int s = 0; s < PF; ++s) {
-    ko[0][s] = lds_b128(smem + fo.b[s]);
-    ko[1][s] = lds_b128(smem + T32 + fo.b[s]);
-  }
-  // the softmax over the keys walked so far is complete: O^T / l -> `dst`, lse -> `lse_out`
-  auto finish = [&](f32x16 (&dst)[NB], float* lse_out) {
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-    const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    const float inv = l > 0.f ? 1.f / l : 0.f;
-    if (lse_out && qok && hi == 0) lse_out[lo] = m_run * LN2 + __logf(l);
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) dst[blk] = o[blk] * inv;
-  };
-  auto stage = [&](auto cur_c, const int t) {
-    constexpr int CUR = decltype(cur_c)::value, NXT = (CUR + 1) % 3, NN = (CUR + 2) % 3;
-    const char* Ks = smem + CUR * STAGE;
-    __syncthreads();
-    const bool more = t + 2 < ntot;
-    if (more) fetch(t + 2);
-    if (w_active) {
-      const bool cross = t < nc;
-      const int rem = cross ? 0 : L - (t - nc) * SR;           // self keys from this stage on
-      const unsigned live_a = cross ? tmask : (rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u));
-      const unsigned live_b = (cross || rem <= 32) ? 0u : (rem >= 64 ? 0xffffffffu : ((1u << (rem - 32)) - 1u));
-      // the next stage's K operands are read ahead (its buffer was committed an iteration ago); after the last stage: this one's
-      const char* Kn = t + 1 < ntot ? smem + NXT * STAGE : Ks;
-      f_step64<D>(ko, Ks, Ks + ST::HALF, Kn, qf, m_run, l_run, live_a, live_b, c2, hi, fo, o);
-      if (cross) {                                             // block-uniform
-        finish(o, p.lse_cross);
-        store_rows32<D>(ocrow, o, 1.f, hi, qok);               // host: out_cross is there whenever the text keys are
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) o[blk] = splat16(0.f);
-        m_run = -1e30f; l_run = 0.f;
-      }
-    }
-    if (more) ST::commit(smem + NN * STAGE, stg, tid);
-  };
-  for (int t = 0; t < ntot; t += 3) {
-    stage(IntC<0>{}, t);
-    if (t + 1 < ntot) stage(IntC<1>{}, t + 1);
-    if (t + 2 < ntot) stage(IntC<2>{}, t + 2);
-  }
-  if (!w_active) return;
-  finish(o, p.lse_self);
-  if (has_c) add_rows32<D>(ocrow, o, hi, qok);
-  store_rows32<D>(reinterpret_cast<T*>(p.out) + (size_t)b * p.o_bs + (size_t)h * D + (size_t)(qok ? qi : 0) * p.o_rs, o, 1.f, hi, qok);
-}
-template <int D> constexpr int attn_fwd32_lds() { return 3 * 2 * Stream32<D, 256>::SR * 2 * D; }
-
 template <int D> constexpr int attn_bwd_dq32_lds() { return 3 * 2 * Stream32<D>::SR * 2 * D; }
 template <int D> constexpr int attn_bwd_dkv32_lds() {
   constexpr int stages = 3 * (2 * Stream32<D>::SR * 2 * D + 8 * Stream32<D>::SR), priv = 8 * (2 * 32 * 2 * D + 256), slots = 8 * 2 * D * 32 * 4;

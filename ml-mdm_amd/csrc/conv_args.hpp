@@ -1,4 +1,4 @@
-// Argument block shared by the forward / input-gradient implicit-GEMM kernels (gemm_conv.hip, gemm_x.hpp).
+// Argument block shared by the forward / input-gradient implicit-GEMM kernels (gemm_conv.hip).
 #pragma once
 #include "common.hpp"
 

@@ -1923,8 +1923,6 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
 
 }  // namespace mdm
 
-#include "gemm_x.hpp"
-
 using namespace mdm;
 
 // ---------------------------------------------------------------------------
@@ -2416,59 +2414,6 @@ static int launch_conv_direct_any(const ConvArgs& a, hipStream_t st) {
   return launch_conv_direct<64, 64, 8, 32, 4>(a, st);
 }
 
-// ---- conv_gemm_x_kernel (gemm_x.hpp): continuous k-tile stream, the epilogue of tile n under the MFMAs of tile n+1 ----
-static int g_force_x = 0;   // development knob 3 (mdm_dev_set_knob): 0 / 1 = never (the product), 2 = whenever the kernel can
-static int g_x_order = 1;   // development knob 4: 0 = row-major tile order, 1 = super-tiles (below)
-template <int MODE, int ACT, bool RES>
-static int launch_conv_x(const ConvArgs& a0, hipStream_t st) {
-  auto kern = conv_gemm_x_kernel<MODE, ACT, RES>;
-  ensure_dynamic_lds(kern, XG::LDS);
-  ConvArgs a = a0;
-  const int tiles_m = a.M / XG::BM, tiles_n = a.Cout / XG::BN;
-  const int tiles = tiles_m * tiles_n;
-  // super-tile shape (SA row tiles x SB column tiles, ~32 tiles = what one XCD runs at a time): SB = the divisor of the
-  // column-tile count closest to 8 from below, SA = the divisor of the row-tile count closest to 32 / SB from below
-  int SB = tiles_n, SA = 1;
-  if (g_x_order == 1) {
-    SB = 1;
-    for (int d = 1; d <= 8 && d <= tiles_n; ++d) if (tiles_n % d == 0) SB = d;
-    const int want = 32 / SB > 0 ? 32 / SB : 1;
-    for (int d = 1; d <= want && d <= tiles_m; ++d) if (tiles_m % d == 0) SA = d;
-  }
-  a.sel_base = SB; a.sel_cout = SA;
-  const int resident = device_cus();
-  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(XG::THREADS), XG::LDS, st, a);
-  MDM_NOTE_KERNEL("conv_gemm_x_kernel<%d, %d, %d>", MODE, ACT, (int)RES);
-  MDM_LAUNCH_STATUS();
-}
-// can the kernel express this problem?  (conv_bl_ok<bf16, MODE>(a) is checked by the caller)
-static bool conv_x_can(const ConvArgs& a) {
-  if (a.M % XG::BM != 0 || a.Cout % XG::BN != 0 || a.K % 64 != 0 || a.K < 64 * XG::MIN_KTILES) return false;
-  if (a.ps_cout > 0 || a.gn_y || a.part) return false;
-  if (a.act == 2 ? (a.res != nullptr || !a.aux) : (a.act == 1 && (a.res != nullptr || !a.ypre))) return false;
-  return (size_t)a.M * a.Cout * 2 < 0x7F000000u;
-}
-// ... and is it the better choice?  Measured (profiles/r04_gemm_x8_probe.txt, r04_gemm_probe_fresh_output_buffers.txt,
-// variants interleaved): rewriting ONE output buffer it wins 9-22 % on the wide 1x1 convolutions with short reductions
-// (768 -> 3072, 512 -> 1536, 512 -> 2048 x gelu'), but with a FRESH output buffer per launch -- what a train step does --
-// the margin shrinks to 3-6 %, the GELU + pre-activation case (two outputs) loses 20 %, and inside the 64x64 U-Net's
-// train step the two kernels are indistinguishable (95.6 vs 95.4 ms, two alternations in one call).  Why: its waits are
-// counted but vmcnt retires in order, so a store to a cold line that takes longer than two k-tile iterations to retire
-// stalls the LDS-DMA behind it, and its 256 x 128 tile moves 1.5x the LDS-DMA bytes per FLOP through a vector-memory
-// path that sustains ~50 GB/s per CU for either kernel.  So conv_gemm_bl_kernel stays the product path; this kernel is
-// kept (parity-tested through development knob 3 = 2) as the measured record of that structure.
-static bool conv_x_wanted(const ConvArgs& a, int ksize) {
-  (void)ksize;
-  return g_force_x == 2 && conv_x_can(a);
-}
-template <int MODE>
-static int launch_conv_x_any(const ConvArgs& a, hipStream_t st) {
-  if (a.act == 1) return launch_conv_x<MODE, 1, false>(a, st);
-  if (a.act == 2) return launch_conv_x<MODE, 2, false>(a, st);
-  if (a.res) return launch_conv_x<MODE, 0, true>(a, st);
-  return launch_conv_x<MODE, 0, false>(a, st);
-}
-
 template <typename T, int MODE, bool SPLIT = false>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE, SPLIT>(a, st);
@@ -2477,7 +2422,6 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if constexpr (MODE != MODE_3x3_T2) {
       if (conv_bl_ok<T, MODE>(a)) {
-        if (conv_x_wanted(a, MODE == MODE_1x1 ? 1 : 3)) return launch_conv_x_any<MODE>(a, st);
         if (code == 256256) return launch_conv_bl<256, 256, 2, 4, MODE>(a, st);
         if (code == 256192) return launch_conv_bl<256, 192, 2, 4, MODE>(a, st);
         return launch_conv_bl<128, 128, 2, 2, MODE>(a, st);
@@ -2708,11 +2652,10 @@ extern "C" int mdm_dev_set_knob(int idx, int value) {
   if (idx == 8) { g_no_wgrad_direct = value; return 0; }
   if (idx == 9) { g_split_minkt = value > 0 ? value : 6; return 0; }
   if (idx == 10) { g_split_minsave = value > 0 ? value : 16; return 0; }
-  if (idx == 3) { g_force_x = value; return 0; }
+  if (idx == 3 || idx == 4) return 0;   // (were: conv_gemm_x_kernel switches; the kernel was removed in round 6)
   if (idx == 6) { g_split_fill = value > 0 ? value : 80; return 0; }
   if (idx == 7) { g_no_direct = value; return 0; }
   if (idx == 2) g_force_tile = value;
-  if (idx == 4) { g_x_order = value; return 0; }
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdm::g_knobs), &value, sizeof(int), idx * sizeof(int));
 }
 

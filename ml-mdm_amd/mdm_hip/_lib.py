@@ -32,7 +32,7 @@ class MdmHipError(RuntimeError):
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source for gfx950 into ml-mdm_amd/mdm_hip/libmdm_hip.so (in-tree)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, h) for h in ("common.hpp", "conv_args.hpp", "gemm_x.hpp", "attn32.hpp")]
+    hdrs = [os.path.join(CSRC, h) for h in ("common.hpp", "conv_args.hpp", "attn32.hpp")]
     deps = srcs + [HEADER] + hdrs
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
@@ -182,8 +182,6 @@ def _apply_dev_env(handle):
     mode = os.environ.get("MDM_HIP_ATTN_BWD")
     if mode:
         handle.mdm_dev_set_attn_bwd({"split": 1, "small": 2, "small16": 3, "stream32": 4, "long16": 5}.get(mode, 0))
-    if os.environ.get("MDM_HIP_ATTN_FWD"):
-        handle.mdm_dev_set_attn_fwd({"fwd16": 1, "fwd32": 2}.get(os.environ["MDM_HIP_ATTN_FWD"], 0))
     if os.environ.get("MDM_HIP_SKIP_WGRAD_REDUCE") == "1":      # timing-only ablation, wrong gradients
         handle.mdm_dev_set_knob(13, 1)
     if os.environ.get("MDM_HIP_GN_CHUNK_MB"):
@@ -202,8 +200,6 @@ def _apply_dev_env(handle):
         handle.mdm_dev_set_knob(11, 1)
     if os.environ.get("MDM_HIP_WGRAD_DIRECT") == "0":   # narrow weight gradients by the split GEMM
         handle.mdm_dev_set_knob(8, 1)
-    if os.environ.get("MDM_HIP_GEMM_X") == "2":   # conv_gemm_x_kernel whenever the problem allows (default: never)
-        handle.mdm_dev_set_knob(3, 2)
 
 
 def check(rc: int, what: str):

@@ -357,6 +357,8 @@ LONG_CASES = {
     # ddim_eta=1 == ancestral DDPM, samplers.py:300) from a checkpoint round-tripped through UNet.save / UNet.load
     # (the real vis_model_1024x1024.pth is not on disk and there is no network: synthetic weights)
     "nested1024_ddpm": ("nested1024", 1, 25, 1, dict(schedule_shifted=True, schedule_shifted_power=2, rescale_signal=1)),
+    # configs[4] as stated: the demo's full 250 DDPM steps (generate_sample.py:546-551), B = 1 (round 6; ~40 min of CPU once)
+    "nested1024_ddpm250": ("nested1024", 1, 250, 1, dict(schedule_shifted=True, schedule_shifted_power=2, rescale_signal=1)),
     # long horizons on the 64x64 U-Net: the demo's 50 steps, ancestral DDPM (ddim_eta=None) and DDIM eta=0
     "unet64_ddpm50": ("unet64", 1, 50, None, {}),
     "unet64_ddim100": ("unet64", 1, 100, 0, {}),

@@ -209,11 +209,10 @@ def test_attention_fp32_split_products(B, L, S, H, d, masked):
         (75, 32, 32, 64, 256, 3),      # 3x3, several tiles per block
     ],
 )
-def test_conv_gemm_x_kernel(act, with_res, N, H, W, Cin, Cout, ks):
-    """conv_gemm_x_kernel (csrc/gemm_x.hpp: continuous k-tile stream, two accumulator sets, the epilogue of tile n under the
-    MFMAs of tile n+1) forced through mdm_conv_fwd (development knob 3 = 2) on problems it accepts (M % 256 == 0,
-    Cout % 128 == 0, K >= 512): every epilogue variant (bias, +residual, GELU + pre-activation, x gelu'(aux)), 1x1 and 3x3,
-    several output tiles per block and fewer tiles than CUs, against the torch fp32 ops it replaces (unet.py:199-217,266-272)."""
+def test_conv_gemm_epilogues(act, with_res, N, H, W, Cin, Cout, ks):
+    """every epilogue variant of the forward / input-gradient GEMM launched directly through mdm_conv_fwd (bias, +residual,
+    GELU + the saved operand of its backward, x gelu'(aux)), 1x1 and 3x3, several output tiles per block and fewer tiles
+    than CUs, against the torch fp32 ops it replaces (unet.py:199-217,266-272)."""
     from mdm_hip import _lib, ops
 
     dtype = torch.bfloat16
@@ -235,15 +234,9 @@ def test_conv_gemm_x_kernel(act, with_res, N, H, W, Cin, Cout, ks):
     wf, wd, bp, cin_p, cout_p, kbf, kbd = ops.packed_weight(w.to(dev()), b.to(dev()), dtype)
     y = torch.full((N, H, W, Cout), float("nan"), device=dev(), dtype=dtype)
     ypre = torch.full_like(y, float("nan")) if act == 1 else None
-    L = _lib.lib()
-    L.mdm_dev_set_knob(3, 2)
-    try:
-        ops._conv_launch(xd, wf, bp, nhwc(res, dtype) if with_res else None, nhwc(aux, dtype) if act == 2 else None, y, ypre,
-                         N, H, W, Cin, H, W, Cout, ks, 1, 0, act, kbf)
-        torch.cuda.synchronize()
-        assert L.mdm_last_gemm_kernel().decode().startswith("conv_gemm_x_kernel"), L.mdm_last_gemm_kernel()
-    finally:
-        L.mdm_dev_set_knob(3, 0)
+    ops._conv_launch(xd, wf, bp, nhwc(res, dtype) if with_res else None, nhwc(aux, dtype) if act == 2 else None, y, ypre,
+                     N, H, W, Cin, H, W, Cout, ks, 1, 0, act, kbf)
+    torch.cuda.synchronize()
     assert relerr(nchw(y), y_ref) < TOL[dtype]
     if act == 1:
         assert relerr(nchw(ypre), pre) < TOL[dtype]
@@ -637,21 +630,7 @@ def test_attention(dtype, B, L, S, H, d, masked, request):
     if S:
         assert relerr(kd.grad.float().cpu(), kvc.grad) < tol
     if dtype == torch.bfloat16:
-        # both forward kernels on the same case (mdm_hip_dev.h: 1 = 16x16x32 MFMAs, 2 = the 32x32x16 kernel of
-        # csrc/attn32.hpp where the shape allows), with the saved lse feeding the default backward
-        for fmode in (1, 2):
-            _lib.lib().mdm_dev_set_attn_fwd(fmode)
-            request.addfinalizer(lambda: _lib.lib().mdm_dev_set_attn_fwd(0))
-            qd1 = qkv.detach().to(dtype).to(dev()).requires_grad_()
-            kd1 = kvc.detach().to(dtype).to(dev()).requires_grad_() if S else None
-            o1 = ops.attention(qd1, kd1, md, H)
-            o1.backward(go.to(dtype).to(dev()))
-            assert relerr(o1.float().cpu(), o_ref) < tol, fmode
-            assert relerr(qd1.grad.float().cpu(), qkv.grad) < tol, fmode
-            if S:
-                assert relerr(kd1.grad.float().cpu(), kvc.grad) < tol, fmode
-        _lib.lib().mdm_dev_set_attn_fwd(0)
-        # ... and every other backward path on the same case (mdm_hip_dev.h: 1 = the two streaming kernels on 16x16x32
+        # every other backward path on the same case (mdm_hip_dev.h: 1 = the two streaming kernels on 16x16x32
         # MFMAs, 3 = one block per head on 16x16x32, 4 = the streaming kernels on 32x32x16 of csrc/attn32.hpp where the
         # shape allows): all must agree with the reference
         for mode in (1, 3, 4):

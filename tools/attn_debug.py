@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Development aid for the attention kernels: both forward kernels (mdm_dev_set_attn_fwd 1 = 16x16x32, 2 = 32x32x16) and
+"""Development aid for the attention kernels: the forward kernel and
 every backward path (mdm_dev_set_attn_bwd 1 = split, 2 = small
 (32x32 MFMA where the shape allows), 3 = small16) against a torch fp32 reference on the same bf16 inputs, error per output
 tensor, and -- when one is off -- a map of the worst 32 x 32 blocks of the first failing (batch, head).
@@ -80,8 +80,7 @@ def case(B, L, S, H, d, masked, seed=6):
     go = torch.randn(o_ref.shape, generator=g).bfloat16().float()
     o_ref.backward(go)
     ok = True
-    for fmode, fname in ((1, "fwd16"), (2, "fwd32")):      # both forward kernels (mdm_dev_set_attn_fwd)
-        _lib.lib().mdm_dev_set_attn_fwd(fmode)
+    for fname in ("fwd16",):      # the forward kernel (the 32x32x16 forward of round 5 was removed in round 6)
         qd = qkv.detach().bfloat16().to(dev)
         kd = kvc.detach().bfloat16().to(dev) if S else None
         o = ops.attention(qd, kd, mask.to(dev) if mask is not None else None, H).float().cpu()
@@ -90,7 +89,6 @@ def case(B, L, S, H, d, masked, seed=6):
         if not e < 3e-2:
             ok = False
             block_map("out", o, o_ref.detach(), H, d, L)
-    _lib.lib().mdm_dev_set_attn_fwd(0)
     for mode, name in MODES.items():
         _lib.lib().mdm_dev_set_attn_bwd(mode)
         qd = qkv.detach().bfloat16().to(dev).requires_grad_()
@@ -137,11 +135,9 @@ def timing(B=64):
         kvc = torch.randn(B, 32, 2 * C, device=dev).bfloat16().requires_grad_()
         fl = 4.0 * B * 8 * L * (L + 32) * d
         line = "attn B=%d L=%d d=%d " % (B, L, d)
-        for fmode, fname in ((1, "fwd16"), (2, "fwd32")):
-            _lib.lib().mdm_dev_set_attn_fwd(fmode)
+        for fname in ("fwd16",):
             tf = timeit(lambda: ops.attention(qkv.detach(), kvc.detach(), None, 8))
             line += " %s %.3f ms %.0f TF" % (fname, tf, fl / tf / 1e9)
-        _lib.lib().mdm_dev_set_attn_fwd(0)
         line += " |"
         for mode, name in MODES.items():
             _lib.lib().mdm_dev_set_attn_bwd(mode)
