@@ -33,8 +33,9 @@
  *   1  round 1
  *   2  mdm_sumsq / mdm_adamw_ema_step gained parameters, mdm_gn_bwd a third accumulate mode (round 2)
  *   4  MDM_F32_SPLIT dtype code (mdm_conv_fwd*, mdm_attn_fwd), mdm_dropout (round 4)
- *   3  round 3 */
-#define MDM_HIP_ABI_VERSION 4
+ *   3  round 3
+ *   5  bf16 tensors: y_pre / aux of mdm_conv_fwd* hold one byte per element, the code of gelu'(pre) (round 6) */
+#define MDM_HIP_ABI_VERSION 5
 
 #ifdef __cplusplus
 extern "C" {
@@ -56,8 +57,12 @@ const char* mdm_last_error(void);
  *   32 for fp32; needs C % B == 0): the 9 taps of a channel block become consecutive k-tiles, which keeps the
  *   shifted re-reads of the activation in L1/L2.  The same value must be passed to mdm_conv_fwd as `kblock`.
  * mdm_conv_fwd:  y = epilogue(conv(x, w_packed)).  epilogue = +bias, act, +res (in this order);
- *   act == MDM_ACT_GELU writes the pre-activation to y_pre when non-null;
- *   act == MDM_ACT_DGELU_AUX multiplies by gelu'(aux) (backward through the FFN GELU, unet.py:270).
+ *   act == MDM_ACT_GELU also leaves, in y_pre when non-null, what the backward through the GELU needs (unet.py:270):
+ *     fp32 tensors: the pre-activation (same shape and dtype as y);
+ *     bf16 tensors: ONE BYTE per element, q = round(196 gelu'(pre)) + 28 (gelu' = (q - 28) / 196: 0 and 1 exact, step
+ *     5.1e-3) -- the backward uses the pre-activation only through gelu', and the launch is store-bound;
+ *   act == MDM_ACT_DGELU_AUX multiplies by gelu'(aux) for fp32 tensors, by the decoded byte aux[m * Cout + n] for bf16
+ *     tensors (aux = the y_pre of the MDM_ACT_GELU launch; backward through the FFN GELU); res must be NULL with it.
  *   The same entry computes the input gradient: pass dy as x and w_dgrad as w_packed
  *   (transposed = 1 for the gradient of a stride-2 convolution: Ho = 2H, Wo = 2W).
  * mdm_conv_wgrad + mdm_conv_wgrad_reduce: dw (Cout, Cin, k, k) fp32 = sum_m dy[m, :] (x) im2col(x)[m, :].

@@ -35,6 +35,9 @@ int mdm_dev_set_attn_bwd(int mode);
  * above which the batch is walked in chunks of samples so that the second kernel's reads still find them in the Infinity
  * Cache (default 160; 0 = chunk whenever the batch allows it -- the tests; negative = never) */
 int mdm_dev_set_gn_chunk_mb(int mb);
+/* bytes per element of the operand a bf16 MDM_ACT_GELU launch leaves for its backward: 1 (the product: the byte code of
+ * gelu', include/mdm_hip.h) or 2 (a variant library built with -DMDM_FFN_AUX_BF16 for in-call A/B: the bf16 pre-activation) */
+int mdm_dev_ffn_aux_bytes(void);
 /* phase time stamps of attn_bwd_small32_kernel: a device buffer of [blocks][8][16] 64-bit words (tools/attn_debug.py), or
  * null (the default) */
 int mdm_dev_set_attn_dbg(void* buf);

@@ -275,8 +275,75 @@ __device__ __forceinline__ float gelu_poly(float z) {
 __device__ __forceinline__ float dgelu_poly(float z) {
   constexpr float Q[8] = {7.989620567e-01f, -2.662556930e-01f, 5.843304141e-02f, -8.376759832e-03f,
                           7.867717586e-04f, -4.620522401e-05f, 1.525062443e-06f, -2.145770312e-08f};
-  return odd_poly8(__builtin_amdgcn_fmed3f(z, -4.f, 4.f), Q);
+  return odd_poly8(__builtin_amdgcn_fmed3f(z, -4.f, 4.f), Q);   // (fmed3 maps NaN to -4: see DGeluCode for where a NaN goes)
 }
+// gelu'(pre) of a bf16 FFN pre-activation as ONE BYTE -- what the FFN-up launch leaves for its backward (round 6).
+// The backward needs the pre-activation only through gelu'(pre); stored as bf16 `pre` that is 2 bytes written by the
+// forward epilogue and 2 bytes read by the x gelu'(aux) epilogue of the input gradient per hidden element -- 100 MB each
+// way per 768 -> 3072 layer at batch 64, in launches whose store phase is additive.  gelu' lies in
+// [-0.129, 1.129]; the code is q = round(196 g) + 28 (0 <-> 28 and 1 <-> 224 exactly, so the saturated tails decode to
+// exactly 0 and 1), step 1 / 196 = 5.1e-3, |error| <= 2.6e-3 + the polynomial's 5e-4 -- the size of the bf16 rounding of
+// a value near 1 (3.9e-3 ulp), unbiased, and only in the gradient (the forward output is bit-identical).  fp32 tensors
+// keep the fp32 pre-activation and the erf form.  A NaN pre-activation encodes as 0 (v_cvt_u32_f32) = gelu' -0.143: the
+// NaN itself travels through the forward output (gelu(NaN) = NaN), the loss, and the step's NaN skip.
+// The same two polynomials on PAIRS of values with packed fp32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth of
+// fp32 FMAs per instruction; the clamp and the final max stay one v_med3 / v_max per element): 7 / 5.5 instructions per
+// element instead of 12 / 10, bit-identical results (the same FMA chain per element).  The GEMM epilogues that apply them are
+// VALU-bound, not store-bound, where they run (round 6: one VALU instruction per element of the 256 x 256 tile costs the
+// 768 -> 3072 launch ~1 us -- a block's 8 waves own the CU and nothing else issues while they compute).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 odd_poly8_pk(f32x2 zc, const float (&c)[8]) {
+  const f32x2 x2 = zc * zc;
+  f32x2 p = {c[7], c[7]};
+#pragma unroll
+  for (int k = 6; k >= 0; --k) p = __builtin_elementwise_fma(p, x2, f32x2{c[k], c[k]});
+  return __builtin_elementwise_fma(zc, p, f32x2{0.5f, 0.5f});
+}
+__device__ __forceinline__ f32x2 clamp4_pk(f32x2 z) {
+  return f32x2{__builtin_amdgcn_fmed3f(z[0], -4.f, 4.f), __builtin_amdgcn_fmed3f(z[1], -4.f, 4.f)};
+}
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 z) {
+  constexpr float P[8] = {3.988065672e-01f, -6.606670007e-02f, 9.583257106e-03f, -1.021626672e-03f,
+                          7.628174443e-05f, -3.717267849e-06f, 1.047660447e-07f, -1.283420065e-09f};
+  const f32x2 c = odd_poly8_pk(clamp4_pk(z), P);
+  return z * f32x2{fmaxf(c[0], 0.f), fmaxf(c[1], 0.f)};
+}
+__device__ __forceinline__ f32x2 dgelu_poly2(f32x2 z) {
+  constexpr float Q[8] = {7.989620567e-01f, -2.662556930e-01f, 5.843304141e-02f, -8.376759832e-03f,
+                          7.867717586e-04f, -4.620522401e-05f, 1.525062443e-06f, -2.145770312e-08f};
+  return odd_poly8_pk(clamp4_pk(z), Q);
+}
+
+#if defined(MDM_FFN_AUX_BF16)   // development A/B (tools/build_variant_src.sh): the bf16 pre-activation as before round 6
+constexpr bool kFfnAuxByte = false;
+#else
+constexpr bool kFfnAuxByte = true;
+#endif
+// v_cvt_pk_u8_f32 converts with round-to-nearest-even and saturation, NaN -> 0 (tools/probes/cvt_pk_u8_probe.hip), and
+// drops the byte into place: one instruction per element for the conversion AND the packing.
+struct DGeluCode {
+  static constexpr float SCALE = 196.f, ZERO = 28.f;
+  static __device__ __forceinline__ unsigned enc(float z) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(fmaf(dgelu_poly(z), SCALE, ZERO), 0, 0u);
+  }
+  static __device__ __forceinline__ float dec(unsigned q) { return fmaf((float)q, 1.f / SCALE, -ZERO / SCALE); }
+  // 4 consecutive elements <-> 4 bytes (N = 4 or 8 values at z / g)
+  static __device__ __forceinline__ unsigned enc4(const float* z) {
+    const f32x2 k = {SCALE, SCALE}, o = {ZERO, ZERO};
+    const f32x2 t0 = __builtin_elementwise_fma(dgelu_poly2(f32x2{z[0], z[1]}), k, o);
+    const f32x2 t1 = __builtin_elementwise_fma(dgelu_poly2(f32x2{z[2], z[3]}), k, o);
+    unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(t0[0], 0, 0u);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(t0[1], 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(t1[0], 2, w);
+    return __builtin_amdgcn_cvt_pk_u8_f32(t1[1], 3, w);
+  }
+  static __device__ __forceinline__ void dec4(unsigned w, float* g) {
+    const f32x2 k = {1.f / SCALE, 1.f / SCALE}, o = {-ZERO / SCALE, -ZERO / SCALE};
+    const f32x2 a = __builtin_elementwise_fma(f32x2{(float)(w & 0xffu), (float)((w >> 8) & 0xffu)}, k, o);
+    const f32x2 b = __builtin_elementwise_fma(f32x2{(float)((w >> 16) & 0xffu), (float)(w >> 24)}, k, o);
+    g[0] = a[0]; g[1] = a[1]; g[2] = b[0]; g[3] = b[1];
+  }
+};
 #if defined(MDM_GELU_EXACT)   // development A/B (tools/build_variant_gemm.sh): the erf form for bf16 tensors too
 template <typename T> __device__ __forceinline__ float gelu_t(float z) { return gelu_f(z); }
 template <typename T> __device__ __forceinline__ float dgelu_t(float z) { return dgelu_f(z); }
@@ -284,6 +351,35 @@ template <typename T> __device__ __forceinline__ float dgelu_t(float z) { return
 template <typename T> __device__ __forceinline__ float gelu_t(float z) { return sizeof(T) == 2 ? gelu_poly(z) : gelu_f(z); }
 template <typename T> __device__ __forceinline__ float dgelu_t(float z) { return sizeof(T) == 2 ? dgelu_poly(z) : dgelu_f(z); }
 #endif
+// v[e] = gelu(v[e]) / v[e] *= gelu'(a[e]) over a chunk (N even): bf16 tensors take the packed polynomial forms
+template <typename T, int N> __device__ __forceinline__ void gelu_vec(float (&v)[N]) {
+#if !defined(MDM_GELU_EXACT) && !defined(MDM_GELU_SCALAR)   // (MDM_GELU_SCALAR: development A/B, the per-element forms)
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int e = 0; e < N; e += 2) {
+      const f32x2 r = gelu_poly2(f32x2{v[e], v[e + 1]});
+      v[e] = r[0]; v[e + 1] = r[1];
+    }
+    return;
+  }
+#endif
+#pragma unroll
+  for (int e = 0; e < N; ++e) v[e] = gelu_t<T>(v[e]);
+}
+template <typename T, int N> __device__ __forceinline__ void mul_dgelu_vec(float (&v)[N], const float (&a)[N]) {
+#if !defined(MDM_GELU_EXACT) && !defined(MDM_GELU_SCALAR)   // (MDM_GELU_SCALAR: development A/B, the per-element forms)
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int e = 0; e < N; e += 2) {
+      const f32x2 r = f32x2{v[e], v[e + 1]} * dgelu_poly2(f32x2{a[e], a[e + 1]});
+      v[e] = r[0]; v[e + 1] = r[1];
+    }
+    return;
+  }
+#endif
+#pragma unroll
+  for (int e = 0; e < N; ++e) v[e] *= dgelu_t<T>(a[e]);
+}
 
 // XCD-aware, bijective remap of a 1-D block id: consecutive logical ids land on
 // the same XCD (hardware places block b on XCD b % 8) so neighbouring tiles that

@@ -45,6 +45,13 @@ struct ConvArgs {
   float* gn_coef;
   float gn_eps;
   int gn_act, gn_groups;
+  // development flags (include/mdm_hip_dev.h knobs 0 and 1; always 0 in the product), filled in by the launch helpers.
+  // They travel in the ARGUMENT block -- a wave-uniform scalar load at kernel start -- and NOT in a __device__ variable:
+  // rounds 3-5 read `g_knobs[1]` (a mutable global, hence a VECTOR load) inside the epilogue's store loop, and the
+  // `s_waitcnt vmcnt(0)` in front of its use made every chunk's store wait for the acknowledgement of the previous one
+  // (round 6)
+  //   bit 0: the epilogue skips its global stores (timing only);  bit 1: the LDS-DMA fetches nothing (timing only)
+  int dev_flags;
 };
 
 enum { MODE_1x1 = 0, MODE_3x3 = 1, MODE_3x3_T2 = 2 };

@@ -44,9 +44,6 @@ __device__ __forceinline__ void load4(const bf16* p, float (&o)[4]) {
 // 16-byte-aligned zeros in device memory: the source of every out-of-range LDS-DMA chunk
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[4] = {};
 
-// development knobs (include/mdm_hip_dev.h: mdm_dev_set_knob), all 0 in the product:
-//   [1] GEMM epilogues skip their global stores (what the store phase of a kernel costs; tools/kbench.py stores)
-__device__ int g_knobs[4] = {0, 0, 0, 0};
 
 // Epilogue shared by the GEMM kernels: bias / activation / residual in registers (fp32), then the finished tile is
 // staged through LDS (free after the k-loop, LDS_BYTES of it) so that HBM sees whole 16-byte chunks of complete
@@ -55,6 +52,18 @@ struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 
 // `after_lds` runs once every wave is done with the LDS (the staged tile is in registers by then): a persistent
 // kernel issues the next tile's first LDS-DMA there, so those loads overlap this tile's stores.
+//
+// Vector-memory ordering is what this function is built around (round 6).  gfx950 has ONE counter (vmcnt) for loads AND
+// stores and it retires in issue order: a wait for a load that was issued AFTER a store is a wait for the store's
+// acknowledgement too.  Rounds 3-5 had such a load in every chunk of the store loop (the development knob read from a
+// __device__ variable -- a vector load --, and the join of the residual paths), so the 16-32 stores of a thread went out one
+// acknowledgement round trip at a time: the "additive store phase at ~4.6 TB/s" of DESIGN.md section 4.1.  Now:
+//   * every operand load (bias, residual / gelu' code) is issued before the staged tile is read back and is waited for,
+//     explicitly, BEFORE the next tile's DMA is queued -- nothing in the store loop loads;
+//   * built and NOT kept: letting a whole tile's stores drain under the next tile's first two k-tiles with counted waits
+//     (their DMA is older than the stores) -- the bookkeeping cost 8-14 more spilled registers in the 256-wide kernels and
+//     the train step nothing or worse (88.8 vs 86.4 ms, profiles/r06_did_not_pay.md); branch-free store loops per epilogue
+//     kind: 82-129 spilled registers, half the speed (tools/mfma_hazard_scan.py's spill cap caught both before the GPU did).
 template <typename T, int BM, int BN, int WM, int WN, int LDS_BYTES, typename AfterLds = NoPrefetch, bool GN = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
                                               int m0, int n0, AfterLds after_lds = AfterLds()) {
@@ -81,6 +90,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
   constexpr int PITCH = BN * (int)sizeof(T) + (POW2 ? 0 : 16);
   constexpr int SWZ = POW2 ? (OCH >= 32 ? 32 : OCH) - 1 : 0;
   static_assert(BM * PITCH <= LDS_BYTES, "output tile must fit the k-loop LDS");
+  // (x gelu'(aux) together with a residual would need two operands per chunk: the entry points reject that combination)
   if ((p.Cout % EPV) == 0) {
     // 1. accumulators + bias -> T -> LDS, branch-free (rows / columns past the edge carry garbage that is never stored)
     f32x4 bv[NT];
@@ -111,10 +121,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
     //    the barrier and the LDS read-back below and cost ONE memory round trip per tile.  Loaded inline in the store loop they
     //    cost one round trip per chunk (16 per tile): the x gelu'(aux) epilogue of the FFN-down input gradient ran at
     //    1.7 TB/s of aux reads (768 -> 3072 at batch 64: 146 us against 85 us without the aux operand).
+    //    bf16 tensors: the operand of x gelu' is the one-byte code of gelu'(pre) (common.hpp DGeluCode) -- 8 bytes per chunk.
     constexpr int NCHP = BM * (BN / EPV) / NT_;
+    constexpr bool AUX8 = sizeof(T) == 2 && kFfnAuxByte;
     const T* const PSRC = (p.act == 2 && AUX) ? AUX : R;
     uint4 pre[NCHP];
-    if (PSRC) {
+    if (AUX8 && p.act == 2 && AUX) {
+      const unsigned char* const A8 = reinterpret_cast<const unsigned char*>(p.aux);
+#pragma unroll
+      for (int i = 0; i < NCHP; ++i) {
+        const int idx = tid + i * NT_;
+        const int row = idx / (BN / EPV), ch = idx - row * (BN / EPV);
+        const int m = m0 + row, n = n0 + ch * EPV;
+        pre[i] = uint4{0u, 0u, 0u, 0u};
+        if (m < p.M && n < p.Cout) {
+          const uint2 t = *reinterpret_cast<const uint2*>(A8 + (size_t)m * p.Cout + n);
+          pre[i].x = t.x; pre[i].y = t.y;
+        }
+      }
+    } else if (PSRC) {
 #pragma unroll
       for (int i = 0; i < NCHP; ++i) {
         const int idx = tid + i * NT_;
@@ -139,6 +164,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
       raw[i] = *reinterpret_cast<const uint4*>(smem + row * PITCH + ((ch ^ (row & SWZ)) << 4));
     }
     __syncthreads();   // the LDS is free again
+    // the operand chunks have had two barriers and the read-back to arrive; from here on the only vector-memory traffic of
+    // this wave is the next tile's DMA (after_lds) and, younger than it, this tile's stores
+    if (PSRC) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     after_lds();
     if constexpr (GN && BM == 256 && BN == 192 && sizeof(T) == 2) {
       {
@@ -252,7 +280,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
       const int row = idx / OCH, ch = idx - row * OCH;
       const int m = m0 + row, n = n0 + ch * EPV;
       if (m >= p.M || n >= p.Cout) continue;
-      if (g_knobs[1]) continue;
+      if (p.dev_flags & 1) continue;   // development knob 1 (a kernel ARGUMENT: see conv_args.hpp)
       size_t o = (size_t)m * p.Cout + n;
       if (p.ps_cout > 0) {   // (phase, co) column of low-res pixel (n, bh, bw) -> its place in the 2x larger image
         const int ph = n / p.ps_cout, co = n - ph * p.ps_cout;
@@ -267,19 +295,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
       Chunk<T> c;
       c.load(reinterpret_cast<const T*>(&raw[i]));
       if (act == 1) {
-        if (Ypre) *reinterpret_cast<uint4*>(Ypre + o) = raw[i];
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) c.v[e] = gelu_t<T>(c.v[e]);
+        if (Ypre) {
+          if constexpr (AUX8) {   // what the backward needs of the pre-activation: gelu'(pre), one byte per element
+            const uint2 code = {DGeluCode::enc4(&c.v[0]), DGeluCode::enc4(&c.v[4])};
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.ypre) + o) = code;
+          } else {
+            *reinterpret_cast<uint4*>(Ypre + o) = raw[i];
+          }
+        }
+        gelu_vec<T, EPV>(c.v);
       } else if (act == 2) {
-        Chunk<T> ax;
-        ax.load(reinterpret_cast<const T*>(&pre[i]));
+        if constexpr (AUX8) {
+          float g[8];
+          DGeluCode::dec4(pre[i].x, g);
+          DGeluCode::dec4(pre[i].y, g + 4);
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) c.v[e] *= dgelu_t<T>(ax.v[e]);
+          for (int e = 0; e < EPV; ++e) c.v[e] *= g[e];
+        } else {
+          Chunk<T> ax;
+          ax.load(reinterpret_cast<const T*>(&pre[i]));
+          mul_dgelu_vec<T, EPV>(c.v, ax.v);
+        }
       }
       if (R) {
         Chunk<T> rr;
-        if (act == 2) rr.load(R + o);                            // both operands: only the first was pre-loaded
-        else rr.load(reinterpret_cast<const T*>(&pre[i]));
+        rr.load(reinterpret_cast<const T*>(&pre[i]));
 #pragma unroll
         for (int e = 0; e < EPV; ++e) c.v[e] += rr.v[e];
       }
@@ -306,10 +346,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         if (e >= nv) continue;
         if (p.bias) v[e] += p.bias[n + e];
         if (p.act == 1) {
-          if (Ypre) Ypre[o + e] = from_f32<T>(v[e]);
+          // (this path sees the unrounded accumulator; the byte code of gelu' is taken from the value rounded to T, as the
+          //  chunked path above takes it)
+          if (Ypre) {
+            if constexpr (sizeof(T) == 2 && kFfnAuxByte) reinterpret_cast<unsigned char*>(p.ypre)[o + e] = (unsigned char)DGeluCode::enc(to_f32(from_f32<T>(v[e])));
+            else Ypre[o + e] = from_f32<T>(v[e]);
+          }
           v[e] = gelu_t<T>(v[e]);
         } else if (p.act == 2) {
-          v[e] *= dgelu_t<T>(to_f32(AUX[o + e]));
+          if constexpr (sizeof(T) == 2 && kFfnAuxByte) v[e] *= DGeluCode::dec(reinterpret_cast<const unsigned char*>(p.aux)[o + e]);
+          else v[e] *= dgelu_t<T>(to_f32(AUX[o + e]));
         }
         if (R) v[e] += to_f32(R[o + e]);
         Y[o + e] = from_f32<T>(v[e]);
@@ -583,7 +629,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
       const int n = n0 + lrow + RPP * j;                                                                    \
       b_voff[j] = n < p.Cout ? (unsigned)n * p.K * 2u + lchunk * 16u : INVALID;                             \
     }                                                                                                       \
-    if (g_knobs[0] & 1) {   /* development knob 0: the LDS-DMA fetches nothing (what the k-loop costs without memory) */ \
+    if (p.dev_flags & 2) {  /* development knob 0: the LDS-DMA fetches nothing (what the k-loop costs without memory) */ \
       _Pragma("unroll") for (int j = 0; j < AJ; ++j) a_voff[j] = INVALID;                                   \
       _Pragma("unroll") for (int j = 0; j < BJ; ++j) b_voff[j] = INVALID;                                   \
     }                                                                                                       \
@@ -672,8 +718,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_bl_kernel(ConvArgs 
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // this tile's first k-tile (and the previous tile's stores, which are older); with NSTG > 2 the later prologue
-    // fetches stay in flight: every k-tile is AJ + BJ LDS-DMA instructions per wave, and vmcnt retires in order
+    // this tile's first k-tile (and the previous tile's stores, which are younger: one in-order counter); with NSTG > 2 the
+    // later prologue fetches stay in flight: every k-tile is AJ + BJ LDS-DMA instructions per wave
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (AJ + BJ) + (NSTG > 2 ? AJ + BJ : 0)) : "memory");
     __syncthreads();
     Frag<T> af[MT], b0[NT], b1[NT];
@@ -1949,14 +1995,26 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   for (int e = 0; e < 4; ++e) v[e] = to_f32(from_f32<T>(s[e]));
   if (act == 1) {
     if (ypre) {
+      if constexpr (sizeof(T) == 2 && kFfnAuxByte) {   // one byte per element: the code of gelu'(pre) (common.hpp DGeluCode)
+        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(ypre) + idx) = DGeluCode::enc4(v);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ypre[idx + e] = from_f32<T>(v[e]);
+        for (int e = 0; e < 4; ++e) ypre[idx + e] = from_f32<T>(v[e]);
+      }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
+    gelu_vec<T, 4>(v);
   } else if (act == 2) {
+    if constexpr (sizeof(T) == 2 && kFfnAuxByte) {
+      float g[4];
+      DGeluCode::dec4(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(aux) + idx), g);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= dgelu_t<T>(to_f32(aux[idx + e]));
+      for (int e = 0; e < 4; ++e) v[e] *= g[e];
+    } else {
+      float ax[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ax[e] = to_f32(aux[idx + e]);
+      mul_dgelu_vec<T, 4>(v, ax);
+    }
   }
   if (res) {
 #pragma unroll
@@ -2071,11 +2129,14 @@ __global__ __launch_bounds__(256) void upconv_bfold_kernel(const float* __restri
 }
 
 static int g_no_deep_pipe = 0;      // development knob 11: 1 = no 4-stage instantiations for under-filled grids
+static int g_dev_flags = 0;         // development knobs 0 / 1 -> ConvArgs::dev_flags (bit 1 / bit 0) of every GEMM launch
+static inline ConvArgs with_dev_flags(const ConvArgs& a) { ConvArgs b = a; b.dev_flags = g_dev_flags; return b; }
 static thread_local char g_last_gemm[96] = "";
 extern "C" const char* mdm_last_gemm_kernel(void) { return g_last_gemm; }
 #define MDM_NOTE_KERNEL(...) snprintf(g_last_gemm, sizeof(g_last_gemm), __VA_ARGS__)
 template <typename T, int BM, int BN, int WM, int WN, int MODE, bool SPLIT = false>
-static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
+static int launch_conv_cfg(const ConvArgs& a_, hipStream_t st) {
+  const ConvArgs a = with_dev_flags(a_);
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, MODE, SPLIT>;
   ensure_dynamic_lds(kern, smem);
@@ -2086,7 +2147,8 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
 }
 
 template <int BM, int BN, int WM, int WN, int MODE>
-static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
+static int launch_conv_bl(const ConvArgs& a_, hipStream_t st) {
+  const ConvArgs a = with_dev_flags(a_);
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE>;
   ensure_dynamic_lds(kern, smem);
@@ -2108,7 +2170,8 @@ static int launch_conv_bl(const ConvArgs& a, hipStream_t st) {
 }
 
 template <int MODE>
-static int launch_conv_bl_gn(const ConvArgs& a, hipStream_t st) {
+static int launch_conv_bl_gn(const ConvArgs& a_, hipStream_t st) {
+  const ConvArgs a = with_dev_flags(a_);
   constexpr int BM = 256, BN = 192, WM = 2, WN = 4;
   constexpr int smem = 2 * (BM + BN) * 128 + 4096;   // + the epilogue's statistics scratch
   auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE, false, false, false, true>;
@@ -2121,7 +2184,8 @@ static int launch_conv_bl_gn(const ConvArgs& a, hipStream_t st) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_conv_bl_sel4(const ConvArgs& a, hipStream_t st) {
+static int launch_conv_bl_sel4(const ConvArgs& a_, hipStream_t st) {
+  const ConvArgs a = with_dev_flags(a_);
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE_3x3, false, false, true>;
   ensure_dynamic_lds(kern, smem);
@@ -2133,7 +2197,8 @@ static int launch_conv_bl_sel4(const ConvArgs& a, hipStream_t st) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_conv_bl_grouped(const ConvArgs& a, const ConvGroup& gr, hipStream_t st) {
+static int launch_conv_bl_grouped(const ConvArgs& a_, const ConvGroup& gr, hipStream_t st) {
+  const ConvArgs a = with_dev_flags(a_);
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE_1x1, true>;
   ensure_dynamic_lds(kern, smem);
@@ -2192,6 +2257,7 @@ extern "C" int mdm_conv_fwd_plan(int M, int Cout, int K, int dtype, int* splits,
 
 template <int MODE>
 static int launch_conv_bl_splitk(ConvArgs a, int splits, float* ws, hipStream_t st) {
+  a.dev_flags = g_dev_flags;
   constexpr int BM = 128, BN = 128, WM = 2, WN = 2;
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = conv_gemm_bl_kernel<BM, BN, WM, WN, MODE, false, true>;
@@ -2453,6 +2519,7 @@ extern "C" int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float*
   if (split_products) dtype = DT_F32;
   MDM_CHECK_ARG(act >= 0 && act <= 2);
   MDM_CHECK_ARG(act != 2 || aux);
+  MDM_CHECK_ARG(!(act == 2 && res));   // one elementwise operand per launch (conv_epilogue keeps loads out of its store loop)
   const int epv = dtype == DT_F32 ? 4 : 8;
   MDM_CHECK_ARG(Cin % epv == 0);
   MDM_CHECK_ARG(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Cout > 0);
@@ -2643,6 +2710,8 @@ extern "C" int mdm_linear_grouped(const void* const* x, const void* const* w_pac
   return launch_conv_bl_grouped<128, 128, 2, 2>(a, gr, st);
 }
 
+extern "C" int mdm_dev_ffn_aux_bytes(void) { return kFfnAuxByte ? 1 : 2; }
+
 static int g_skip_wgrad_reduce = 0;   // development knob 13: timing-only ablation, the slab reduces are not launched (WRONG gradients)
 extern "C" int mdm_dev_set_knob(int idx, int value) {
   MDM_CHECK_ARG(idx >= 0 && idx < 14);
@@ -2652,11 +2721,13 @@ extern "C" int mdm_dev_set_knob(int idx, int value) {
   if (idx == 8) { g_no_wgrad_direct = value; return 0; }
   if (idx == 9) { g_split_minkt = value > 0 ? value : 6; return 0; }
   if (idx == 10) { g_split_minsave = value > 0 ? value : 16; return 0; }
-  if (idx == 3 || idx == 4) return 0;   // (were: conv_gemm_x_kernel switches; the kernel was removed in round 6)
+  if (idx == 3 || idx == 4) return 0;   // (were conv_gemm_x_kernel switches; the kernel was removed in round 6)
   if (idx == 6) { g_split_fill = value > 0 ? value : 80; return 0; }
   if (idx == 7) { g_no_direct = value; return 0; }
-  if (idx == 2) g_force_tile = value;
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdm::g_knobs), &value, sizeof(int), idx * sizeof(int));
+  if (idx == 2) { g_force_tile = value; return 0; }
+  if (idx == 0) { g_dev_flags = (g_dev_flags & ~2) | ((value & 1) ? 2 : 0); return 0; }
+  if (idx == 1) { g_dev_flags = (g_dev_flags & ~1) | (value ? 1 : 0); return 0; }
+  return 0;
 }
 
 // ---- direct weight gradient for the narrow outer levels of the nested models (64 output channels at 128^2 ... 1024^2) ----

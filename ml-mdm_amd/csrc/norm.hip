@@ -27,6 +27,9 @@
 
 namespace mdm {
 
+template <int N> struct GnInt { static constexpr int value = N; };   // compile-time operand counts / flags of the store loops
+
+
 // ---- stage 1: per (n, slab) per-channel shifted sums -------------------------
 // part[n][slab][c] = (s1, s2) with s1 = sum(x - K_c), s2 = sum((x - K_c)^2), K_c = x[n, 0, c]
 template <typename T>
@@ -358,6 +361,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   // Four pixel rows per trip, every operand of the four requested before the first is used (8-16 loads of 16 bytes in
   // flight per thread): one row per trip -- two dependent-latency loads, then the arithmetic, then the store -- left this
   // kernel at 2.3-3.1 TB/s of its own traffic where the forward apply kernel (same map, four rows deep) reaches 5.
+  // (Round 6: software-pipelining the trips over two register sets, so that a trip's operands are requested before the
+  // previous trip's stores -- gfx950's single in-order vmcnt makes a later load wait for them -- cost 70 more registers and
+  // was 3-8 % SLOWER on cold buffers: with 8-16 waves per SIMD other waves already cover the acknowledgement round trip.)
   for (int p = px0 + rl; p < px1; p += 4 * rows_par) {
     uint4 rx[4], rd[4], rr[4], rs[4];
 #pragma unroll
@@ -632,34 +638,66 @@ __global__ __launch_bounds__(NTHR) void gn_fused_bwd_kernel(const T* __restrict_
   const float m = (float)cpg * (float)HW;
   const float qq = -rstd * rstd * S2 / m;
   const float rr = -rstd * S1 / m - qq * mu;
+  // The residual-branch gradients (dres: the block's own residual; dres2: a second consumer of x outside the block, the
+  // U-Net's skip connection) are added here instead of by a separate kernel.  gfx950 counts loads and stores in ONE in-order
+  // counter (vmcnt): a load issued after a store cannot be waited for without waiting for the store's acknowledgement as
+  // well, so the pass-by-pass form (load, wait, add, store) of rounds 3-5 paid one full memory round trip per pass, one after
+  // the other.  Now the operands are requested in BATCHES of NB passes, each batch before the stores of the batch ahead of
+  // it, in straight-line code (a variant per operand count, chosen by block-uniform branches: across the per-pass branches of
+  // a predicated loop hipcc falls back to vmcnt(0) at every use).  Registers: 2 x NB x 4 per operand beyond x and dy, live
+  // only here (requesting everything up front with x and dy cost a wave per SIMD and was slower: r05).
+  constexpr int NB = NI < 4 ? NI : (NI > 4 ? 2 : 4);
+  auto tail = [&](auto nres_c, auto exact_c) {
+    constexpr int NRES = decltype(nres_c)::value;
+    constexpr bool EXACT = decltype(exact_c)::value;   // HW == NI * R: no pixel predicate anywhere
+    uint4 q1[2][NB], q2[2][NB];
+    auto fetch = [&](int it0, int buf) {
 #pragma unroll
-  for (int it = 0; it < NI; ++it) {
-    const int p = r + it * R;
-    if (p < HW) {
-      Chunk<T> vx, vd;
-      vx.load(reinterpret_cast<const T*>(&rx[it]));
-      vd.load(reinterpret_cast<const T*>(&rd[it]));
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        float dz = vd.v[e];
-        if (ACT) dz *= dsilu_f(a[e] * vx.v[e] + b[e]);
-        vd.v[e] = a[e] * dz + qq * vx.v[e] + rr;
+      for (int j = 0; j < NB; ++j) {
+        const int p = r + (it0 + j) * R;
+        const size_t off = base + (size_t)(EXACT || p < HW ? p : 0) * C;   // (a row that is not stored reads row 0: no branch)
+        if constexpr (NRES >= 1) q1[buf][j] = *reinterpret_cast<const uint4*>(dres + off);
+        if constexpr (NRES >= 2) q2[buf][j] = *reinterpret_cast<const uint4*>(dres2 + off);
       }
-      if (dres) {   // gradient that reaches x through the residual branch: added here instead of by a separate kernel
-        Chunk<T> vr;
-        vr.load(dres + base + (size_t)p * C);
+    };
+    if constexpr (NRES >= 1) fetch(0, 0);
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) vd.v[e] += vr.v[e];
-      }
-      if (dres2) {   // ... and through a second consumer of x outside the block (the U-Net's skip connection)
-        Chunk<T> vr;
-        vr.load(dres2 + base + (size_t)p * C);
+    for (int it0 = 0; it0 < NI; it0 += NB) {
+      const int cur = (it0 / NB) & 1;
+      if constexpr (NRES >= 1) { if (it0 + NB < NI) fetch(it0 + NB, cur ^ 1); }
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) vd.v[e] += vr.v[e];
+      for (int j = 0; j < NB; ++j) {
+        const int it = it0 + j;
+        const int p = r + it * R;
+        Chunk<T> vx, vd;
+        vx.load(reinterpret_cast<const T*>(&rx[it]));
+        vd.load(reinterpret_cast<const T*>(&rd[it]));
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          float dz = vd.v[e];
+          if (ACT) dz *= dsilu_f(a[e] * vx.v[e] + b[e]);
+          vd.v[e] = a[e] * dz + qq * vx.v[e] + rr;
+        }
+        if constexpr (NRES >= 1) {
+          Chunk<T> vr;
+          vr.load(reinterpret_cast<const T*>(&q1[cur][j]));
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) vd.v[e] += vr.v[e];
+        }
+        if constexpr (NRES >= 2) {
+          Chunk<T> vr;
+          vr.load(reinterpret_cast<const T*>(&q2[cur][j]));
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) vd.v[e] += vr.v[e];
+        }
+        if (EXACT || p < HW) vd.store(dx + base + (size_t)p * C);
       }
-      vd.store(dx + base + (size_t)p * C);
     }
-  }
+  };
+  const bool exact = HW == NI * R;
+  if (dres2) { if (exact) tail(GnInt<2>{}, GnInt<1>{}); else tail(GnInt<2>{}, GnInt<0>{}); }
+  else if (dres) { if (exact) tail(GnInt<1>{}, GnInt<1>{}); else tail(GnInt<1>{}, GnInt<0>{}); }
+  else { if (exact) tail(GnInt<0>{}, GnInt<1>{}); else tail(GnInt<0>{}, GnInt<0>{}); }
 }
 
 // Shape of a fused launch: channels per block (cb: whole groups, <= 8 of them), block size and passes.  cb = 0: not
@@ -968,6 +1006,7 @@ extern "C" int mdm_gn_bwd(const void* dy, const void* x, const float* gamma, con
   MDM_CHECK_ARG(dy && x && gamma && beta && stats && coef && dx && dgamma && dbeta && ws);
   MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16);
   MDM_CHECK_ARG((film == nullptr) == (dfilm == nullptr));
+  if (!dres && dres2) { dres = dres2; dres2 = nullptr; }   // the kernels count operands: a second one implies the first
   const int epv = dtype == DT_F32 ? 4 : 8;
   MDM_CHECK_ARG(C % epv == 0 && C % G == 0 && C <= 2048 && G <= 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -935,7 +935,10 @@ class FFNFn(torch.autograd.Function):
         wf1, _, bp1, c_in, c_hid, _, _ = packed_weight(w1, b1, x.dtype)
         wf2, _, bp2, _, c_out, _, _ = packed_weight(w2, b2, x.dtype)
         N, H, W, _, _ = _geom(x, 1, 1)
-        pre = torch.empty(_out_shape(x, H, W, c_hid), dtype=x.dtype, device=x.device) if keep else None
+        # what backward needs of the pre-activation: itself for fp32 tensors; for bf16 tensors one byte per element, the
+        # code of gelu'(pre) (include/mdm_hip.h, MDM_ACT_GELU) -- half the bytes of this store-bound launch's second output
+        byte_code = x.dtype == torch.bfloat16 and _lib.lib().mdm_dev_ffn_aux_bytes() == 1
+        pre = torch.empty(_out_shape(x, H, W, c_hid), dtype=torch.uint8 if byte_code else x.dtype, device=x.device) if keep else None
         a = torch.empty(_out_shape(x, H, W, c_hid), dtype=x.dtype, device=x.device)
         _conv_launch(x, wf1, bp1, None, None, a, pre, N, H, W, c_in, H, W, c_hid, 1, 1, 0, 1)
         y = torch.empty(_out_shape(x, H, W, c_out), dtype=x.dtype, device=x.device)
@@ -952,7 +955,7 @@ class FFNFn(torch.autograd.Function):
         _, wd2, _, _, c_out, _, _ = packed_weight(w2, b2, x.dtype)
         N, H, W, _, _ = _geom(x, 1, 1)
         M = N * H * W
-        dpre = torch.empty_like(pre)
+        dpre = torch.empty_like(a)
         _conv_launch(dy, wd2, None, None, pre, dpre, None, N, H, W, c_out, H, W, c_hid, 1, 1, 0, 2)
         def wb_grads(xin, g, w, b, cin_, cout_):
             """(dW, db) of a 1x1 conv from ONE wgrad launch; None entries went into the gradient arena"""

@@ -510,12 +510,12 @@ def test_graphed_sampler_passes_micro_conditioning_and_handles_one_step_schedule
     assert O.rel_l2(outs[("scale", 4)], outs[("default", 4)]) > 1e-4
 
 
-@pytest.mark.parametrize("name", ["nested1024_ddpm", "unet64_ddpm50", "unet64_ddim100"])
+@pytest.mark.parametrize("name", ["nested1024_ddpm", "unet64_ddpm50", "unet64_ddim100", "nested1024_ddpm250"])
 def test_long_horizon_sampling_matches_reference(name, tmp_path):
     """Long sampling runs at FULL size against the real reference pipeline (tests/golden/long_sampling.pt, made by
     oracle/make_golden.py long): BASELINE.json configs[4] -- the 64+256+1024 NestedUNet, ancestral DDPM (ddim_eta=1,
-    generate_sample.py:546-551), 25 steps, B=1, weights round-tripped through UNet.save -> UNet.load -- and the 64x64
-    U-Net over 50 DDPM / 100 DDIM steps.  The reference consumed, draw by draw, the host replay of the numbers the step
+    generate_sample.py:546-551), 25 steps, B=1, weights round-tripped through UNet.save -> UNet.load -- the same over the
+    demo's full 250 steps (configs[4] as stated; round 6) -- and the 64x64 U-Net over 50 DDPM / 100 DDIM steps.  The reference consumed, draw by draw, the host replay of the numbers the step
     kernel generates from DeviceRng(LONG_SEED) (oracle/philox_ref.py), so both sides see identical noise.
     Gate: 1e-3 rel-L2 in fp32 (north_star); the bf16-autocast error of the same run is printed."""
     import make_golden as MG

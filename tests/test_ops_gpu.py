@@ -222,24 +222,77 @@ def test_conv_gemm_epilogues(act, with_res, N, H, W, Cin, Cout, ks):
     b = torch.randn(Cout, generator=g)
     pre = q(F.conv2d(x, w, b, padding=(ks - 1) // 2), dtype)            # the conv output as the bf16 graph has it
     res = q(torch.randn(pre.shape, generator=g), dtype) if with_res else None
-    aux = q(torch.randn(pre.shape, generator=g), dtype) if act == 2 else None
+    aux = q(torch.randn(pre.shape, generator=g) * 1.5, dtype) if act == 2 else None
+
+    def dgelu(t):
+        a = t.clone().requires_grad_()
+        return torch.autograd.grad(F.gelu(a).sum(), a)[0]
+
+    # bf16 tensors: the operand the GELU launch leaves for its backward is ONE BYTE per element, the code
+    # q = round(196 gelu'(pre)) + 28 (include/mdm_hip.h MDM_ACT_GELU; csrc/common.hpp DGeluCode)
+    code = None
     if act == 1:
         y_ref = F.gelu(pre)
     elif act == 2:
-        a = aux.clone().requires_grad_()
-        y_ref = pre * torch.autograd.grad(F.gelu(a).sum(), a)[0]
+        code = torch.round(dgelu(aux) * 196.0 + 28.0).clamp(0, 255).to(torch.uint8)
+        y_ref = pre * dgelu(aux)
     else:
         y_ref = pre + (res if with_res else 0)
     xd = nhwc(x, dtype)
     wf, wd, bp, cin_p, cout_p, kbf, kbd = ops.packed_weight(w.to(dev()), b.to(dev()), dtype)
     y = torch.full((N, H, W, Cout), float("nan"), device=dev(), dtype=dtype)
-    ypre = torch.full_like(y, float("nan")) if act == 1 else None
-    ops._conv_launch(xd, wf, bp, nhwc(res, dtype) if with_res else None, nhwc(aux, dtype) if act == 2 else None, y, ypre,
+    ypre = torch.full((N, H, W, Cout), 255, device=dev(), dtype=torch.uint8) if act == 1 else None
+    auxd = code.permute(0, 2, 3, 1).contiguous().to(dev()) if act == 2 else None
+    ops._conv_launch(xd, wf, bp, nhwc(res, dtype) if with_res else None, auxd, y, ypre,
                      N, H, W, Cin, H, W, Cout, ks, 1, 0, act, kbf)
     torch.cuda.synchronize()
     assert relerr(nchw(y), y_ref) < TOL[dtype]
     if act == 1:
-        assert relerr(nchw(ypre), pre) < TOL[dtype]
+        # decoded gelu' against the erf form of the bf16 pre-activation the kernel saw: half a code step (2.55e-3), the
+        # polynomial's 5.1e-4, and the bf16 rounding of the pre-activation on the kernel's side (the reference `pre` here is
+        # rounded from an fp32 convolution: the two roundings may differ by one ulp, |gelu''| <= 1.13 of it)
+        got = (ypre.permute(0, 3, 1, 2).float().cpu() - 28.0) / 196.0
+        err = (got - dgelu(pre)).abs()
+        ulp = pre.abs().clamp(min=2.0 ** -10) * 2.0 ** -7
+        assert bool((err <= 2.56e-3 + 5.2e-4 + 1.13 * ulp).all()), float(err.max())
+        assert float(err.mean()) < 1.6e-3      # ~ a quarter step on average: the code is unbiased
+    if act == 2:
+        # ... and the decode side exactly: the product with the decoded byte, rounded once
+        y_code = q(pre * ((code.float() - 28.0) / 196.0), dtype)
+        assert relerr(nchw(y), y_code) < 5e-3     # (two bf16 roundings of slightly different fp32 sums)
+
+
+def test_gelu_poly_against_erf_gelu():
+    """The transcendental-free GELU / GELU' of the bf16 epilogues (csrc/common.hpp gelu_poly, dgelu_poly) against the erf
+    forms (nn.GELU(), unet.py:270) on EVERY bf16 value in [-9, 9], evaluated by the kernels themselves: an identity 1x1
+    convolution (exact in bf16: one nonzero product per output) feeds each value to the GELU epilogue.  Gates: gelu within
+    1.5e-4 absolute + the bf16 rounding of the result; gelu' (decoded from its byte code) within 6e-4 + half a code step."""
+    from mdm_hip import ops
+
+    dtype = torch.bfloat16
+    bits = torch.arange(0, 1 << 16, dtype=torch.int32)
+    vals = bits.to(torch.int16).view(torch.bfloat16).float()
+    vals = vals[torch.isfinite(vals) & (vals.abs() <= 9.0)]
+    C = 64
+    n = (vals.numel() + C - 1) // C
+    n = (n + 255) // 256 * 256
+    z = torch.zeros(n * C)
+    z[:vals.numel()] = vals
+    x = z.view(n, C).to(dtype).to(dev())
+    w = torch.eye(C).view(C, C, 1, 1).to(dev())
+    wf, wd, bp, cin_p, cout_p, kbf, kbd = ops.packed_weight(w, None, dtype)
+    y = torch.empty((n, C), device=dev(), dtype=dtype)
+    ypre = torch.empty((n, C), device=dev(), dtype=torch.uint8)
+    ops._conv_launch(x, wf, None, None, None, y, ypre, n, 1, 1, C, 1, 1, C, 1, 1, 0, 1, kbf)
+    torch.cuda.synchronize()
+    zz = z.view(n, C).double()
+    cdf = 0.5 * (1.0 + torch.erf(zz / math.sqrt(2.0)))
+    gelu = zz * cdf
+    dgelu = cdf + zz * torch.exp(-0.5 * zz * zz) / math.sqrt(2.0 * math.pi)
+    e1 = (y.double().cpu() - gelu).abs()
+    assert bool((e1 <= 1.5e-4 + gelu.abs() * 2.0 ** -8).all()), float((e1 - gelu.abs() * 2.0 ** -8).max())
+    e2 = ((ypre.double().cpu() - 28.0) / 196.0 - dgelu).abs()
+    assert bool((e2 <= 6e-4 + 0.5 / 196.0 + 1e-6).all()), float(e2.max())
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 256, 256), (3, 8, 16, 512, 256), (2, 16, 8, 768, 768)])

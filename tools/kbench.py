@@ -102,8 +102,13 @@ def main():
                 w = (torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5)
                 wf, wd, bp, cin_p, cout_p, kbf, kbd = ops.packed_weight(w, torch.randn(cout, device=dev), DT)
                 ys = [torch.empty(B, H, H, cout, device=dev, dtype=DT) for _ in range(ring)]
-                yps = [torch.empty(B, H, H, cout, device=dev, dtype=DT) for _ in range(ring)] if act == 1 else [None] * ring
-                auxs = [torch.randn(B, H, H, cout, device=dev).to(DT) for _ in range(ring)] if act >= 2 else [None] * ring
+                from mdm_hip import _lib
+                byte = DT == torch.bfloat16 and _lib.lib().mdm_dev_ffn_aux_bytes() == 1   # gelu' as a byte code (round 6)
+                yps = [torch.empty(B, H, H, cout * (2 if os.environ.get('KB_KNOB3_UNUSED') else 1), device=dev, dtype=torch.uint8 if byte else DT) for _ in range(ring)] if act == 1 else [None] * ring
+                if act == 2 and byte:
+                    auxs = [torch.randint(3, 250, (B, H, H, cout), device=dev, dtype=torch.uint8) for _ in range(ring)]
+                else:
+                    auxs = [torch.randn(B, H, H, cout, device=dev).to(DT) for _ in range(ring)] if act >= 2 else [None] * ring
                 flops = 2.0 * B * H * H * cout * cin
                 it = [0]
                 def one():
@@ -112,10 +117,12 @@ def main():
                         ops._conv_launch(x, wf, bp, auxs[j], None, ys[j], None, B, H, H, cin, H, H, cout, 1, 1, 0, 0, kbf)
                     else:
                         ops._conv_launch(x, wf, bp if act != 2 else None, None, auxs[j], ys[j], yps[j], B, H, H, cin, H, H, cout, 1, 1, 0, act, kbf)
+                if os.environ.get("KB_KNOB3_UNUSED"):
+                    _lib.lib().mdm_dev_set_knob(3, int(os.environ["KB_KNOB3_UNUSED"]))
                 t = timeit(one, iters=3 * ring)
                 it[0] = 0
                 t1 = timeit(lambda: (it.__setitem__(0, 0), one())[1], iters=3 * ring)
-                out_mb = ys[0].numel() * 2 * (2 if act == 1 else 1) / 1e6
+                out_mb = (ys[0].numel() * 2 + (yps[0].numel() * yps[0].element_size() if act == 1 else 0)) / 1e6
                 print("%-20s act=%d out %6.0f MB  fresh buffers %7.1f us %6.0f TF | same buffer %7.1f us %6.0f TF" % (
                     name, act, out_mb, t * 1e6, flops / t / 1e12, t1 * 1e6, flops / t1 / 1e12), flush=True)
     if what in ("stores",):
