@@ -23,6 +23,8 @@
 // transposed V tile.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mdm {
@@ -423,6 +425,23 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     float* LSE = pass ? p.lse_cross : p.lse_self;
     T* O = reinterpret_cast<T*>(p.out) + (size_t)b * p.o_bs + (size_t)h * D;
     const T* OCR = (OCM && p.kc) ? reinterpret_cast<const T*>(p.out_cross) + (size_t)b * p.o_bs + (size_t)h * D : nullptr;
+    // OCM, last pass: the cross part of every output piece is requested HERE, before the first store.  Read inside the
+    // store loop (rounds 2-5) each piece was load -> wait -> add -> store, and gfx950's single in-order vmcnt makes the wait
+    // for a load that follows a store a wait for that store's acknowledgement: QT x DT dependent round trips at the end of
+    // every block (12 at d = 96; tools/store_wait_scan.py).
+    using OcV = typename std::conditional<sizeof(T) == 2, bf16x4, f32x4>::type;
+    OcV ocv[OCM ? QT : 1][OCM ? DT : 1];
+    if constexpr (OCM) {
+      if (pass == 0 && OCR) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          const int qi = min(q0 + qt * 16 + l16, p.L - 1);     // (rows past the end are not stored; clamped, not predicated)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            ocv[qt][dt] = *reinterpret_cast<const OcV*>(OCR + (size_t)qi * p.o_rs + dt * 16 + quad * 4);
+        }
+      }
+    }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float l = l_run[qt];
@@ -446,9 +465,8 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         if (pass == 0 && qi < p.L) {   // last pass: the output row
           T* dst = O + (size_t)qi * p.o_rs + dt * 16 + quad * 4;
           if (OCM && OCR) {
-            const T* src = OCR + (size_t)qi * p.o_rs + dt * 16 + quad * 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) val[i] += to_f32(src[i]);
+            for (int i = 0; i < 4; ++i) val[i] += (float)ocv[OCM ? qt : 0][OCM ? dt : 0][i];
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) dst[i] = from_f32<T>(val[i]);

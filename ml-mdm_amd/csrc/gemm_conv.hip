@@ -1651,23 +1651,61 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_wgrad_bl_kernel(Wgrad
     reinterpret_cast<int*>(p.bslab - WG_BHDR)[0] = bias_share;
   // grouped launches (splits == 1) add the finished tile straight into the layer's gradient-arena slot: every output
   // element has exactly one owner, so a plain read-modify-write suffices
+  // The two forms are separate loops on purpose (round 6): written as one loop with `direct ? *o + acc : acc`, the wait for
+  // the (possibly absent) load sat at the join of the two branches, in front of EVERY store -- and gfx950's single in-order
+  // vmcnt turns a wait behind a store into a wait for that store's acknowledgement: the 32-128 stores of a thread went
+  // out one memory round trip at a time, in the slab form too (tools/store_wait_scan.py: 162 such waits in this kernel).
   const bool direct = p.groups > 0;
   float* __restrict__ S = direct ? gr.out[grp] : p.slab + (size_t)split * p.Cout * p.K;
   const bool vec_ok = (p.K & 3) == 0;
+  if (!direct) {
+    // slab form: plain stores, nothing is loaded
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int n = n0 + wm * TM + i * 16 + l16;
-    if (n >= p.Cout) continue;
+    for (int i = 0; i < MT; ++i) {
+      const int n = n0 + wm * TM + i * 16 + l16;
+      if (n >= p.Cout) continue;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int k = k0 + wn * TN + j * 16 + quad * 4;
-      if (k >= p.K) continue;
-      float* o = S + (size_t)n * p.K + k;
-      if (vec_ok) {
-        *reinterpret_cast<f32x4*>(o) = direct ? *reinterpret_cast<const f32x4*>(o) + acc[i][j] : acc[i][j];
-      } else {
+      for (int j = 0; j < NT; ++j) {
+        const int k = k0 + wn * TN + j * 16 + quad * 4;
+        if (k >= p.K) continue;
+        float* o = S + (size_t)n * p.K + k;
+        if (vec_ok) {
+          *reinterpret_cast<f32x4*>(o) = acc[i][j];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (k + e < p.K) o[e] = direct ? o[e] + acc[i][j][e] : acc[i][j][e];
+          for (int e = 0; e < 4; ++e) if (k + e < p.K) o[e] = acc[i][j][e];
+        }
+      }
+    }
+  } else if (vec_ok && n0 + BM <= p.Cout && k0 + BN <= p.K) {
+    // arena form, whole tile (the grouped launches' layers are multiples of the tile): row i + 1's old values are
+    // requested BEFORE row i's sums are stored, so no load is ever younger than a store it has to wait behind
+    float* const o0 = S + (size_t)(n0 + wm * TM + l16) * p.K + k0 + wn * TN + quad * 4;
+    f32x4 old[2][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) old[0][j] = *reinterpret_cast<const f32x4*>(o0 + j * 16);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (i + 1 < MT) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) old[(i + 1) & 1][j] = *reinterpret_cast<const f32x4*>(o0 + (size_t)(i + 1) * 16 * p.K + j * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(o0 + (size_t)i * 16 * p.K + j * 16) = old[i & 1][j] + acc[i][j];
+    }
+  } else {
+    // arena form, ragged tile: element by element (every output element has exactly one owner)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int n = n0 + wm * TM + i * 16 + l16;
+      if (n >= p.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int k = k0 + wn * TN + j * 16 + quad * 4;
+        if (k >= p.K) continue;
+        float* o = S + (size_t)n * p.K + k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k + e < p.K) o[e] += acc[i][j][e];
       }
     }
   }
