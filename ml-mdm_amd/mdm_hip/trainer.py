@@ -25,6 +25,7 @@ therefore leaves the scaler alone (the plain path drives it like the reference d
 
 ``TrainStep`` is the same fused step as a self-contained object (tests, tools).
 """
+import collections
 import math
 import os
 
@@ -99,6 +100,20 @@ class FusedState:
         buf, ev = self._host_vals[name]
         ev.synchronize()
         return float(buf[0])
+
+    def post_skip_flag(self):
+        """-> (pinned host scalar, event) that will hold THIS step's squared norm of the reduced gradient (non-finite = the
+        device skipped the update).  A ring of buffers, because the flag of step N is looked at two calls later (`_settle`)
+        while steps N + 1 and N + 2 post theirs."""
+        ring = self.__dict__.setdefault("_skip_ring", [])
+        k = self.__dict__.get("_skip_next", 0)
+        if len(ring) <= k:
+            ring.append((torch.empty(1, dtype=torch.float32).pin_memory(), torch.cuda.Event()))
+        buf, ev = ring[k]
+        self._skip_next = (k + 1) % 4
+        buf.copy_(self.gnorm_sq.detach().reshape(1), non_blocking=True)
+        ev.record()
+        return buf, ev
 
     def optimizer_step(self, lr, betas, eps, weight_decay, clip_norm, ema_decay, dtype, loss=None):
         """clip + AdamW + EMA + zero-grad over the arenas (two launches) and the re-pack of the kernel-layout weights.
@@ -191,7 +206,7 @@ def _adopt(model, optimizer, ema_model):
         step_host = torch.tensor(float(steps))
         for p in params:
             optimizer.state[p]["step"] = step_host
-        optimizer.register_state_dict_pre_hook(lambda opt, st=st, t=step_host: (_settle(st), t.fill_(float(int(st.step_dev)))) and None)
+        optimizer.register_state_dict_pre_hook(lambda opt, st=st, t=step_host: (_settle(st, keep=0), t.fill_(float(int(st.step_dev)))) and None)
 
         def _reinstall(opt, st=st, params=params, t=step_host):
             # optimizer.load_state_dict() replaced the state entries with fresh tensors: copy them into the arenas the
@@ -345,8 +360,7 @@ def _train_batch_fused(st, model, sample, optimizer, scheduler, logger, args, ac
         st.optimizer_step(grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"], float(getattr(args, "gradient_clip_norm", 2.0)),
                           decay, torch.bfloat16 if fp16 else torch.float32, loss=loss)
         optimizer._opt_called = True   # the step happened (silences lr_scheduler's call-order warning)
-        if lockstep:
-            st.post_scalar("gnorm_sq", st.gnorm_sq)
+        skip_flag = st.post_skip_flag()
     if loss_val is None:
         loss_val = st.read_scalar("loss")
     if not lockstep and math.isnan(loss_val):
@@ -360,16 +374,22 @@ def _train_batch_fused(st, model, sample, optimizer, scheduler, logger, args, ac
             logger.add_scalar("train/Loss", loss_val)
             logger.add_scalar("lr", lr)
         scheduler.step()
-    if lockstep:
+    if not accumulate_gradient:
+        # (One rank: the same flag covers what the loss value does not show -- an inf loss, or a finite loss whose gradients
+        # overflowed: the device skips the update on the non-finite norm, and the host takes its bookkeeping back when it
+        # sees the flag, exactly as below.  A NaN loss was dealt with above, on both sides.)
         # What a NaN anywhere did to this step is in the norm of the all-reduced gradient, identical on every rank -- but
         # it exists only when the whole step has run, and waiting for it here would cost the host its one-step lead over
         # the GPU (measured: +3...5 ms per step).  So the host-side consequences above (scheduler.step(), EMA counter) are
-        # taken as if the step was applied, and corrected when the next call -- or optimizer.state_dict() -- finds that
-        # it was skipped (_settle): the reference's NaN branch (trainer.py:38-41: no scheduler step, no EMA update in
-        # bf16), one call late, on all ranks alike.
-        st.unsettled = (scheduler, ema_model, fp16)
+        # taken as if the step was applied, and corrected TWO calls later -- or when optimizer.state_dict() is taken -- if
+        # the step turns out skipped (_settle): the reference's NaN branch (trainer.py:38-41: no scheduler step, no EMA
+        # update in bf16), late by a fixed number of calls, on all ranks alike.  (Round 5 settled ONE call later: the
+        # event of step N - 1 is recorded behind its optimizer, and at the start of call N the host has only waited for
+        # forward N - 1 -- it blocked there for the whole previous backward + all-reduce + optimizer, the very wait this
+        # scheme exists to avoid.  Two calls later the GPU is a whole step past the event.)
+        st.__dict__.setdefault("unsettled", collections.deque()).append((skip_flag, scheduler, ema_model, fp16))
         if _STRICT_NAN:
-            _settle(st)
+            _settle(st, keep=0)
     return loss_val, losses, times, x_t, means, targets
 
 
@@ -378,30 +398,31 @@ def _train_batch_fused(st, model, sample, optimizer, scheduler, logger, args, ac
 _STRICT_NAN = os.environ.get("MDM_HIP_STRICT_NAN", "0") == "1"
 
 
-def _settle(st):
-    """lock-step ranks: if the LAST synchronised step turned out skipped on the device (non-finite norm of the reduced
-    gradient), take back what the host did for it as if it had been applied: the EMA warm-up counter, and -- bf16 branch,
-    as the reference's NaN return -- the scheduler step.  Called at the start of the next train_batch and from the
-    optimizer's state_dict() hook, when the flag has long arrived (no stall)."""
+def _settle(st, keep=1):
+    """lock-step ranks: take back what the host did for synchronised steps that turned out skipped on the device (non-finite
+    norm of the reduced gradient) as if they had been applied: the EMA warm-up counter, and -- bf16 branch, as the
+    reference's NaN return -- the scheduler step.  The `keep` most recent steps stay unexamined: called with keep = 1 at the
+    start of train_batch N it looks at step N - 2, whose flag arrived a whole step ago (no host stall; the same fixed delay
+    on every rank, so learning rates never differ between ranks); keep = 0 (the optimizer's state_dict() hook,
+    MDM_HIP_STRICT_NAN=1) waits for everything."""
     pend = getattr(st, "unsettled", None)
-    if pend is None:
-        return
-    st.unsettled = None
-    if math.isfinite(st.read_scalar("gnorm_sq")):
-        return
-    scheduler, ema_model, fp16 = pend
-    if ema_model is not None:
-        ema_model.counter -= 1
-    if fp16:
-        # undo one scheduler.step(): schedulers whose rate is a function of last_epoch (LambdaLR and the closed-form ones)
-        closed = getattr(scheduler, "_get_closed_form_lr", None)
-        scheduler.last_epoch -= 1
-        if hasattr(scheduler, "_step_count"):
-            scheduler._step_count -= 1
-        lrs = closed() if closed is not None else scheduler.get_lr()
-        for g, lr in zip(scheduler.optimizer.param_groups, lrs):
-            g["lr"] = lr
-        scheduler._last_lr = [g["lr"] for g in scheduler.optimizer.param_groups]
+    while pend is not None and len(pend) > keep:
+        (buf, ev), scheduler, ema_model, fp16 = pend.popleft()
+        ev.synchronize()
+        if math.isfinite(float(buf[0])):
+            continue
+        if ema_model is not None:
+            ema_model.counter -= 1
+        if fp16:
+            # undo one scheduler.step(): schedulers whose rate is a function of last_epoch (LambdaLR and the closed-form ones)
+            closed = getattr(scheduler, "_get_closed_form_lr", None)
+            scheduler.last_epoch -= 1
+            if hasattr(scheduler, "_step_count"):
+                scheduler._step_count -= 1
+            lrs = closed() if closed is not None else scheduler.get_lr()
+            for g, lr in zip(scheduler.optimizer.param_groups, lrs):
+                g["lr"] = lr
+            scheduler._last_lr = [g["lr"] for g in scheduler.optimizer.param_groups]
 
 
 def _fused_nan_return(st, optimizer, scheduler, fp16, loss_val, losses, times, x_t, means, targets, clear):
