@@ -273,7 +273,8 @@ class GradReducer:
                 if self._avg_ok is None:
                     self._avg_ok = (dist.get_backend(self.group) == "nccl" and hasattr(dist.ReduceOp, "AVG")
                                     and os.environ.get("MDM_HIP_NO_AVG") != "1")   # (development A/B switch)
-                if self._avg_ok:
+                if self._avg_ok and self.nranks > 1:   # (a world of one has nothing to scale; RCCL's AVG of one rank still runs
+                    #                                      a kernel over the bucket: +3.9 ms per step, round 6)
                     h = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
                 else:
                     if self.nranks > 1:
