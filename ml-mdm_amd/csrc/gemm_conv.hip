@@ -2167,6 +2167,7 @@ __global__ __launch_bounds__(256) void upconv_bfold_kernel(const float* __restri
 }
 
 static int g_no_deep_pipe = 0;      // development knob 11: 1 = no 4-stage instantiations for under-filled grids
+static int g_one_tile_blocks = 0;   // development knob 5
 static int g_dev_flags = 0;         // development knobs 0 / 1 -> ConvArgs::dev_flags (bit 1 / bit 0) of every GEMM launch
 static inline ConvArgs with_dev_flags(const ConvArgs& a) { ConvArgs b = a; b.dev_flags = g_dev_flags; return b; }
 static thread_local char g_last_gemm[96] = "";
@@ -2202,7 +2203,10 @@ static int launch_conv_bl(const ConvArgs& a_, hipStream_t st) {
     }
   }
   const int resident = device_cus() * (WM * WN == 4 ? 2 : 1);   // persistent blocks: one (8 waves) or two (4 waves) per CU
-  hipLaunchKernelGGL(kern, dim3(tiles < resident ? tiles : resident), dim3(WM * WN * 64), smem, st, a, NoConvGroup{});
+  // development knob 5: 1 = one block per output tile (a block's stores drain while its successor on the CU starts), 0 =
+  // persistent blocks (the next tile's first DMA is issued from inside the epilogue)
+  const int grid = (g_one_tile_blocks || tiles < resident) ? tiles : resident;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, st, a, NoConvGroup{});
   MDM_NOTE_KERNEL("conv_gemm_bl_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, MODE);
   MDM_LAUNCH_STATUS();
 }
@@ -2759,6 +2763,7 @@ extern "C" int mdm_dev_set_knob(int idx, int value) {
   if (idx == 8) { g_no_wgrad_direct = value; return 0; }
   if (idx == 9) { g_split_minkt = value > 0 ? value : 6; return 0; }
   if (idx == 10) { g_split_minsave = value > 0 ? value : 16; return 0; }
+  if (idx == 5) { g_one_tile_blocks = value; return 0; }
   if (idx == 3 || idx == 4) return 0;   // (were conv_gemm_x_kernel switches; the kernel was removed in round 6)
   if (idx == 6) { g_split_fill = value > 0 ? value : 80; return 0; }
   if (idx == 7) { g_no_direct = value; return 0; }

@@ -36,7 +36,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
     deps = srcs + [HEADER] + hdrs
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-            _write_build_note(deps, refresh=True)
+            # the note is renewed only when something it records can have changed since it was written (a commit: .git/HEAD
+            # or the index moved) -- not on every import: hashing every source and spawning `git describe` in each of N
+            # ranks' imports was pure start-up cost
+            note = LIB_PATH + ".build.json"
+            marks = [os.path.join(_ROOT, ".git", "HEAD"), os.path.join(_ROOT, ".git", "index")]
+            try:
+                stale = any(os.path.exists(m) and os.path.getmtime(m) > os.path.getmtime(note) for m in marks)
+            except OSError:
+                stale = os.path.isdir(os.path.join(_ROOT, ".git"))
+            if stale:
+                _write_build_note(deps, refresh=True)
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
@@ -90,9 +100,11 @@ def _write_build_note(deps, refresh=False):
             return
         if not note["git_describe"] or old.get("sources_sha256") != note["sources_sha256"] or old.get("git_describe") == note["git_describe"]:
             return
-    try:
-        with open(LIB_PATH + ".build.json", "w") as f:
+    try:   # through a temporary file: several ranks may import at once, and a reader must never see half a note
+        tmp = "%s.build.json.%d.tmp" % (LIB_PATH, os.getpid())
+        with open(tmp, "w") as f:
             json.dump(note, f)
+        os.replace(tmp, LIB_PATH + ".build.json")
     except OSError:
         pass
 
@@ -186,6 +198,8 @@ def _apply_dev_env(handle):
         handle.mdm_dev_set_knob(13, 1)
     if os.environ.get("MDM_HIP_GN_CHUNK_MB"):
         handle.mdm_dev_set_gn_chunk_mb(int(os.environ["MDM_HIP_GN_CHUNK_MB"]))
+    if os.environ.get("MDM_HIP_ONE_TILE_BLOCKS"):
+        handle.mdm_dev_set_knob(5, int(os.environ["MDM_HIP_ONE_TILE_BLOCKS"]))
     if os.environ.get("MDM_HIP_SPLIT_FILL"):
         handle.mdm_dev_set_knob(6, int(os.environ["MDM_HIP_SPLIT_FILL"]))
     if os.environ.get("MDM_HIP_CONV_DIRECT") == "0":
