@@ -280,7 +280,7 @@ __device__ __forceinline__ float dgelu_poly(float z) {
 // gelu'(pre) of a bf16 FFN pre-activation as ONE BYTE -- what the FFN-up launch leaves for its backward (round 6).
 // The backward needs the pre-activation only through gelu'(pre); stored as bf16 `pre` that is 2 bytes written by the
 // forward epilogue and 2 bytes read by the x gelu'(aux) epilogue of the input gradient per hidden element -- 100 MB each
-// way per 768 -> 3072 layer at batch 64, in launches whose store phase is additive.  gelu' lies in
+// way per 768 -> 3072 layer at batch 64, in launches whose store phase is additive (HISTORY.md section 4.1).  gelu' lies in
 // [-0.129, 1.129]; the code is q = round(196 g) + 28 (0 <-> 28 and 1 <-> 224 exactly, so the saturated tails decode to
 // exactly 0 and 1), step 1 / 196 = 5.1e-3, |error| <= 2.6e-3 + the polynomial's 5e-4 -- the size of the bf16 rounding of
 // a value near 1 (3.9e-3 ulp), unbiased, and only in the gradient (the forward output is bit-identical).  fp32 tensors

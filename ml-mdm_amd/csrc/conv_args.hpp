@@ -49,7 +49,7 @@ struct ConvArgs {
   // They travel in the ARGUMENT block -- a wave-uniform scalar load at kernel start -- and NOT in a __device__ variable:
   // rounds 3-5 read `g_knobs[1]` (a mutable global, hence a VECTOR load) inside the epilogue's store loop, and the
   // `s_waitcnt vmcnt(0)` in front of its use made every chunk's store wait for the acknowledgement of the previous one
-  // (round 6)
+  // (round 6; HISTORY.md section 4.1)
   //   bit 0: the epilogue skips its global stores (timing only);  bit 1: the LDS-DMA fetches nothing (timing only)
   int dev_flags;
 };

@@ -57,7 +57,7 @@ struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 // stores and it retires in issue order: a wait for a load that was issued AFTER a store is a wait for the store's
 // acknowledgement too.  Rounds 3-5 had such a load in every chunk of the store loop (the development knob read from a
 // __device__ variable -- a vector load --, and the join of the residual paths), so the 16-32 stores of a thread went out one
-// acknowledgement round trip at a time: the "additive store phase at ~4.6 TB/s" of DESIGN.md section 4.1.  Now:
+// acknowledgement round trip at a time: the "additive store phase at ~4.6 TB/s" of HISTORY.md section 4.1 (rounds 3-5).  Now:
 //   * every operand load (bias, residual / gelu' code) is issued before the staged tile is read back and is waited for,
 //     explicitly, BEFORE the next tile's DMA is queued -- nothing in the store loop loads;
 //   * built and NOT kept: letting a whole tile's stores drain under the next tile's first two k-tiles with counted waits

@@ -311,7 +311,7 @@ def train_batch(model, sample, optimizer, scheduler, logger, args, grad_scaler=N
 
 
 # the loss is read AFTER backward and the optimizer tail are queued (0: where the reference reads it, before backward --
-# the host then cannot queue the backward until the forward has drained; A/B switch)
+# the host then cannot queue the backward until the forward has drained; A/B switch, HISTORY.md section 6.1)
 _LATE_LOSS_READ = os.environ.get("MDM_HIP_EARLY_LOSS_SYNC", "0") != "1"
 
 

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), n
     L = _lib.lib()
-    assert L.mdm_abi_version() == _lib.ABI_VERSION == 4
+    assert L.mdm_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_plan_functions_are_host_only():

@@ -265,6 +265,9 @@ def _nan_worker(rank, world, port, out):
         vals.append(trainer.train_batch(pipe, s_i, opt, sched, None, args, ema_model=ema)[0])
     torch.cuda.synchronize()
     st = opt._mdm_fused
+    # a step's skip flag is examined two calls later (round 6: one call later made the host wait for the whole previous
+    # step) -- or when the optimizer's state is taken, as a checkpoint does: that is the settled view compared below
+    opt.state_dict()
     res = {"loss": vals, "lr": sched.get_last_lr()[0], "ema_counter": ema.counter, "step": int(st.step_dev),
            "p": st.flat_p.detach().cpu().clone()}
     gathered = [None] * world
@@ -279,7 +282,8 @@ def test_nan_on_one_rank_keeps_the_ranks_in_lockstep(tmp_path):
     """(advisor, rounds 3 and 4) bf16 fused step on two ranks, a NaN loss on rank 1 only: both ranks must skip the update
     (device side), keep identical parameters, and treat scheduler and EMA counter identically -- the reference's per-rank
     early return (trainer.py:38-41) would deadlock DDP.  Both ranks learn of the skip from the norm of the REDUCED gradient
-    -- when the next call finds it (no end-of-step wait: the host keeps its lead over the GPU) -- and then do what the
+    -- two calls later, or when optimizer.state_dict() is taken (no end-of-step wait: the host keeps its lead over the
+    GPU) -- and then do what the
     reference's NaN branch does (bf16: no scheduler.step(), no EMA-counter increment), so the learning rate schedule and
     the EMA warm-up do not depend on the world size."""
     import math

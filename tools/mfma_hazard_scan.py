@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Static check of the compiled kernels for the hazard found in round 3: an MFMA result read back (v_accvgpr_read, VALU,
 LDS / global store) with too few wait states when the read sits on the TAKEN edge of a branch -- ROCm 7.2's hazard
-recognizer covered the fall-through path only (conv3x3_direct_kernel<64, 64, 8, 32, 4>).
+recognizer covered the fall-through path only (conv3x3_direct_kernel<64, 64, 8, 32, 4>, HISTORY.md section 4.1e).
 Walks every path of up to 10 wait states after each v_mfma (following branches) and reports reads of its destination
 registers that come earlier than `MIN_WS` (the compiler itself leaves 11 in straight-line code).  CPU-only:
    python tools/mfma_hazard_scan.py            # compiles csrc/gemm_conv.hip and attention.hip to ISA, exits 1 on a finding
