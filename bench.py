@@ -45,7 +45,7 @@ FWD_GFLOP_PER_SAMPLE = {"unet64": 363.9, "nested256": 589.1, "mini": 0.0}
 PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0       # HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s measured for a float4 copy)
-PMC_FILES = ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
+PMC_FILES = ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
 
 
 def build(workload, device, seed=0):
