@@ -203,7 +203,8 @@ int mdm_ln_multi_bwd(const void* const* dy, const void* x, const float* const* g
  * replaces SelfAttention.attention x2 + the sum (unet.py:276-307): einsum QK^T, fp32 softmax, einsum PV.
  *   qkv [B, L, 3C] = (q | k | v), kvc [B, S, 2C] = (k_c | v_c) or NULL, mask [B, S] (0/1 floats) or NULL
  *   out = softmax(q k^T / sqrt(d)) v + softmax(q k_c^T / sqrt(d) masked) v_c          [B, L, C], C = H * d
- *   out_cross (optional, needed for backward) = the cross term alone; lse_* [B, H, L] fp32.
+ *   out_cross (required with kvc: the kernel stages the cross term through it, and the backward reads it) = the cross
+ *   term alone; lse_* [B, H, L] fp32 (optional in the forward).
  * mdm_attn_bwd overwrites dqkv [B, L, 3C] and dkvc [B, S, 2C]; delta_* are fp32 [B, H, L] scratch.
  * d must be one of 32, 64, 96, 128.
  */

@@ -429,9 +429,12 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
     // store loop (rounds 2-5) each piece was load -> wait -> add -> store, and gfx950's single in-order vmcnt makes the wait
     // for a load that follows a store a wait for that store's acknowledgement: QT x DT dependent round trips at the end of
     // every block (12 at d = 96; tools/store_wait_scan.py).
+    // (bf16 only: 2 registers per piece.  The fp32 kernels -- parity mode and the bf16x3 sampling mode, 4 registers per
+    //  piece -- are at their register limit and keep the read in the store loop.)
+    constexpr bool OCB = OCM && sizeof(T) == 2;
     using OcV = typename std::conditional<sizeof(T) == 2, bf16x4, f32x4>::type;
-    OcV ocv[OCM ? QT : 1][OCM ? DT : 1];
-    if constexpr (OCM) {
+    OcV ocv[OCB ? QT : 1][OCB ? DT : 1];
+    if constexpr (OCB) {
       if (pass == 0 && OCR) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -465,8 +468,14 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnAr
         if (pass == 0 && qi < p.L) {   // last pass: the output row
           T* dst = O + (size_t)qi * p.o_rs + dt * 16 + quad * 4;
           if (OCM && OCR) {
+            if constexpr (OCB) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) val[i] += (float)ocv[OCM ? qt : 0][OCM ? dt : 0][i];
+              for (int i = 0; i < 4; ++i) val[i] += (float)ocv[OCB ? qt : 0][OCB ? dt : 0][i];
+            } else {
+              const T* src = OCR + (size_t)qi * p.o_rs + dt * 16 + quad * 4;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) val[i] += to_f32(src[i]);
+            }
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) dst[i] = from_f32<T>(val[i]);
@@ -1255,8 +1264,8 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   using G = AttnGeom<T, D>;
   constexpr int smem = sizeof(T) == 2 ? 4 * G::NAT_BYTES : G::NAT_BYTES + (G::NAT_BYTES > G::TR_BYTES ? G::NAT_BYTES : G::TR_BYTES);
   ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, true, SPLIT>, smem);
-  ensure_dynamic_lds(attn_fwd_kernel<T, D, 2, false, SPLIT>, smem);
-  const bool ocm = !a.kc || a.out_cross;   // nothing to keep, or a buffer to keep it in
+  // (the entry point requires out_cross whenever there are text keys: the cross part is staged through it, so no second
+  //  accumulator set lives across the self loop -- the register-resident form spilled at d = 96 and was deleted in round 6)
   // Small batch (sampling at batch 1-4: 64 blocks of 128 queries at L = 256, batch 4, on 256 CUs): 16 queries per wave
   // instead of 32 -- twice the blocks, half the serial work of each; the grid is what is short there, not the LDS reads
   // per MFMA that 32 queries per wave save.
@@ -1264,16 +1273,13 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
     const long blocks2 = (long)((a.L + 127) / 128) * a.B * a.H;
     if (blocks2 * 2 <= device_cus() && a.L > 64) {
       ensure_dynamic_lds(attn_fwd_kernel<T, D, 1, true, SPLIT>, smem);
-      ensure_dynamic_lds(attn_fwd_kernel<T, D, 1, false, SPLIT>, smem);
       dim3 grid1((a.L + 63) / 64, a.B * a.H);
-      if (ocm) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, true, SPLIT>), grid1, dim3(256), smem, st, a);
-      else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, false, SPLIT>), grid1, dim3(256), smem, st, a);
+      hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, true, SPLIT>), grid1, dim3(256), smem, st, a);
       MDM_LAUNCH_STATUS();
     }
   }
   dim3 grid((a.L + 127) / 128, a.B * a.H);   // 32 queries per wave: every K / V fragment feeds two MFMAs
-  if (ocm) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, true, SPLIT>), grid, dim3(256), smem, st, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, false, SPLIT>), grid, dim3(256), smem, st, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, true, SPLIT>), grid, dim3(256), smem, st, a);
   MDM_LAUNCH_STATUS();
 }
 
@@ -1369,6 +1375,7 @@ extern "C" int mdm_attn_fwd(const void* qkv, const void* kvc, const float* mask,
   if (split_products) dtype = DT_F32;
   MDM_CHECK_ARG(B > 0 && L > 0 && H > 0);
   MDM_CHECK_ARG(!kvc || S > 0);
+  MDM_CHECK_ARG(!kvc || out_cross);   // the cross part is staged through out_cross (and the backward needs it)
   const int C = H * d;
   const size_t es = dtype == DT_F32 ? 4 : 2;
   AttnArgs a = {};
