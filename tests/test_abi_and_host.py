@@ -193,7 +193,11 @@ def test_no_mfma_result_is_read_back_early_on_a_branch_edge():
     within 6 wait states on ANY path, taken branch edges included.  ROCm 7.2's hazard recognizer missed exactly that in
     conv3x3_direct_kernel<64, 64, 8, 32, 4> (stale accumulators, caught by the GPU parity test; the kernel now fences its
     k-loop from its epilogue) -- this keeps a recompile from reintroducing it silently.  The same pass checks that no kernel
-    of the two sources spills more than 24 vector registers (today's worst: 15).  Cross-compiles, no GPU needed."""
+    of the two sources spills more than 24 vector registers (today's worst: 18), that the bias-gradient dot products of the
+    weight-gradient kernel stay behind scalar branches, and -- round 6 -- that no GEMM epilogue has a vector load between the
+    wide stores of its chunked store loop (on gfx950's single in-order vmcnt such a load makes every store wait for the
+    acknowledgement of the one before it: 2.1 ms per train step in rounds 3-5; the round-5 ISA trips this check 760 times).
+    Cross-compiles, no GPU needed."""
     import importlib.util
     import shutil
 

@@ -8,7 +8,8 @@ registers that come earlier than `MIN_WS` (the compiler itself leaves 11 in stra
 Also checks, on the same ISA, that no kernel spills more than SPILL_CAP vector registers, and that the bias-gradient dot
 products of conv_wgrad_bl_kernel still sit behind scalar branches (round 5: as plain code hipcc if-converted them into every
 wave's instruction stream -- all 64 v_dot2c + a v_cndmask per row -- which is what made one block in nine the tail of the
-launch; a parity test does not see that either)."""
+launch; a parity test does not see that either), and -- round 6 -- that no GEMM epilogue loads between the wide stores of its
+chunked store loop (loads_between_wide_stores)."""
 import collections
 import os
 import re
@@ -102,6 +103,33 @@ def unguarded_dot2(path):
     return out
 
 
+def loads_between_wide_stores(path):
+    """Round 6: the chunked store loops of the GEMM epilogues (conv_gemm_bl_kernel / conv_gemm_kernel) and of the slab form of
+    conv_wgrad_bl_kernel must not LOAD between their 8 / 16-byte stores.  gfx950 counts loads and stores in one in-order
+    counter (vmcnt), so the wait for a load that follows a store is a wait for that store's acknowledgement -- rounds 3-5 had
+    a vector load (a development knob read from a __device__ variable) and a join-point wait in front of every chunk, and the
+    "additive store phase" they produced cost 2.1 ms per train step.  A parity test cannot see this.  Flags every vector load
+    that sits between two wide global stores with a vmcnt wait behind it (the per-element paths use narrow stores and are
+    not looked at; the arena form of the weight gradient loads one row AHEAD of its stores by design and is exempt)."""
+    txt = open(path).read()
+    out = []
+    for km in re.finditer(r"^(\S*(?:conv_gemm_bl_kernel|conv_gemm_kernel)\S*):\s*; @\1\n", txt, re.M):
+        name, i = km.group(1), km.end()
+        code = [ln.strip() for ln in txt[i:txt.find(".Lfunc_end", i)].split("\n")]
+        code = [ln for ln in code if ln and not ln.startswith(";") and not ln.startswith(".")]
+        last_wide, pending_load = False, None
+        for ln in code:
+            if ln.startswith("global_store_dwordx4") or ln.startswith("global_store_dwordx2"):
+                if last_wide and pending_load is not None:
+                    out.append((name, pending_load))
+                last_wide, pending_load = True, None
+            elif ln.startswith("global_store") or ln.startswith("s_barrier") or ln.startswith("v_mfma"):
+                last_wide, pending_load = False, None
+            elif last_wide and (ln.startswith("global_load") or (ln.startswith("buffer_load") and " lds" not in ln)):
+                pending_load = ln
+    return out
+
+
 def main():
     srcs = sys.argv[1:] or ["gemm_conv.hip", "attention.hip"]
     bad = 0
@@ -134,6 +162,11 @@ def main():
                 for name, ln in ung[:4]:
                     print("      %s: %s" % (name[:60], ln))
                 bad += len(ung)
+                lw = loads_between_wide_stores(out)
+                print("   GEMM epilogues: %d vector loads between two wide stores of a chunked store loop" % len(lw))
+                for name, ln in lw[:4]:
+                    print("      %s: %s" % (name[:60], ln))
+                bad += len(lw)
     return 1 if bad else 0
 
 
