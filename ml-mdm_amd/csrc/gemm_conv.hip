@@ -2068,9 +2068,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 __device__ __forceinline__ bool up_tap_in(int ph, int a, int kh) {
   return ph == 0 ? (a == 0 ? kh == 0 : kh >= 1) : (a == 0 ? kh <= 1 : kh == 2);
 }
-// one thread per (co, ci): w (Cout, Cin, 3, 3) fp32 -> w_ph [4 Cout][Cin / 64][4][64] and w_t [Cin][4][Cout / 64][4][64] (bf16)
+// one thread per (co, ci), ci the fast index: w (Cout, Cin, 3, 3) fp32 -> w_ph [4 Cout][Cin / 64][4][64] (bf16)
 __global__ __launch_bounds__(256) void upconv_pack_kernel(const float* __restrict__ w, bf16* __restrict__ w_ph,
-                                                          bf16* __restrict__ w_t, int Cout, int Cin) {
+                                                          int Cout, int Cin) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Cout * Cin) return;
   const int co = idx / Cin, ci = idx - co * Cin;
@@ -2094,35 +2094,61 @@ __global__ __launch_bounds__(256) void upconv_pack_kernel(const float* __restric
           const int phase = ph * 2 + pw;
           // forward: row (phase, co), k = (ci / 64, tap j = 2a + b, ci % 64)
           w_ph[((size_t)(phase * Cout + co) * (Cin >> 6) + (ci >> 6)) * 256 + (a * 2 + b) * 64 + (ci & 63)] = (bf16)v;
-          // input gradient: row ci, k = (phase, co / 64, tap j = 2 dj + dk with dj = 1 - a, dk = 1 - b, co % 64)
-          w_t[(((size_t)ci * 4 + phase) * (Cout >> 6) + (co >> 6)) * 256 + ((1 - a) * 2 + (1 - b)) * 64 + (co & 63)] = (bf16)v;
         }
 }
+// ... and its input-gradient pack w_t [Cin][4 phases][Cout / 64][4][64]: row ci, k = (phase, co / 64, tap j = 2 dj + dk with
+// dj = 1 - a, dk = 1 - b, co % 64) -- co is the fast index there, so it is written from a [64 co][16 ci][9] brick staged in
+// LDS (64 runs of 256 contiguous bf16 per brick), like s2dgrad_pack_kernel below.  (As part of the kernel above, whose
+// threads run along ci, these were scattered two-byte stores: 54-58 us per weight.)
+__global__ __launch_bounds__(256) void upconv_pack_t_kernel(const float* __restrict__ w, bf16* __restrict__ w_t, int Cout,
+                                                            int Cin) {
+  __shared__ float t[64][16 * 9 + 1];
+  const int cib = Cin / 16;
+  const int co0 = ((int)blockIdx.x / cib) * 64, ci0 = ((int)blockIdx.x % cib) * 16;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * 144; e += 256) {
+    const int co_l = e / 144, r = e - co_l * 144;
+    t[co_l][r] = w[((size_t)(co0 + co_l) * Cin + ci0) * 9 + r];
+  }
+  __syncthreads();
+  for (int e = tid; e < 4 * 16 * 256; e += 256) {
+    const int co_l = e & 63, j = (e >> 6) & 3, ci_l = (e >> 8) & 15, phase = e >> 12;
+    const int ph = phase >> 1, pw = phase & 1, a = 1 - (j >> 1), b = 1 - (j & 1);
+    float v = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+        if (up_tap_in(ph, a, kh) && up_tap_in(pw, b, kw)) v += t[co_l][ci_l * 9 + kh * 3 + kw];
+    w_t[(((size_t)(ci0 + ci_l) * 4 + phase) * (Cout >> 6) + (co0 >> 6)) * 256 + j * 64 + co_l] = (bf16)v;
+  }
+}
 
-// one thread per (co, ci): w (Cout, Cin, 3, 3) fp32 -> the input-gradient pack of the stride-2 convolution,
+// w (Cout, Cin, 3, 3) fp32 -> the input-gradient pack of the stride-2 convolution,
 // w_sel [(ph, pw, ci)][Cout / 64][tap j = 2 dh + dw][64] bf16: dx[2b + p] += dy[b + d] * W[k(p, d)] per axis with
-// k(0, 0) = 1, k(1, 0) = 2, k(1, 1) = 0 and no tap for (p, d) = (0, 1) (zero block)
+// k(0, 0) = 1, k(1, 0) = 2, k(1, 1) = 0 and no tap for (p, d) = (0, 1) (zero block).
+// A block moves a [64 co][16 ci][9] brick through LDS: read as 64 runs of 144 contiguous floats, written as 64 runs of
+// 256 contiguous bf16 (one per (phase, ci)).  (Rounds 3-5: one thread per (co, ci) with ci the fast index -- every one of
+// its 16 two-byte stores went to a different 512-byte row: 108-134 us for a 256 x 256 weight, twice per train step.)
 __global__ __launch_bounds__(256) void s2dgrad_pack_kernel(const float* __restrict__ w, bf16* __restrict__ w_sel, int Cout,
                                                            int Cin) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Cout * Cin) return;
-  const int co = idx / Cin, ci = idx - co * Cin;
-  float t[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) t[k] = w[(size_t)idx * 9 + k];
-#pragma unroll
-  for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-    for (int pw = 0; pw < 2; ++pw)
-#pragma unroll
-      for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-        for (int dw = 0; dw < 2; ++dw) {
-          const int kh = ph == 0 ? (dh == 0 ? 1 : -1) : (dh == 0 ? 2 : 0);
-          const int kw = pw == 0 ? (dw == 0 ? 1 : -1) : (dw == 0 ? 2 : 0);
-          const float v = (kh >= 0 && kw >= 0) ? t[kh * 3 + kw] : 0.f;
-          w_sel[(((size_t)((ph * 2 + pw) * Cin + ci) * (Cout >> 6) + (co >> 6)) * 4 + dh * 2 + dw) * 64 + (co & 63)] = (bf16)v;
-        }
+  __shared__ float t[64][16 * 9 + 1];
+  const int cib = Cin / 16;
+  const int co0 = ((int)blockIdx.x / cib) * 64, ci0 = ((int)blockIdx.x % cib) * 16;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * 144; e += 256) {
+    const int co_l = e / 144, r = e - co_l * 144;
+    t[co_l][r] = w[((size_t)(co0 + co_l) * Cin + ci0) * 9 + r];
+  }
+  __syncthreads();
+  for (int e = tid; e < 4 * 16 * 256; e += 256) {
+    const int co_l = e & 63, j = (e >> 6) & 3, ci_l = (e >> 8) & 15, phase = e >> 12;
+    const int ph = phase >> 1, pw = phase & 1, dh = j >> 1, dw = j & 1;
+    const int kh = ph == 0 ? (dh == 0 ? 1 : -1) : (dh == 0 ? 2 : 0);
+    const int kw = pw == 0 ? (dw == 0 ? 1 : -1) : (dw == 0 ? 2 : 0);
+    const float v = (kh >= 0 && kw >= 0) ? t[co_l][ci_l * 9 + kh * 3 + kw] : 0.f;
+    w_sel[(((size_t)(phase * Cin + ci0 + ci_l) * (Cout >> 6) + (co0 >> 6)) * 4 + j) * 64 + co_l] = (bf16)v;
+  }
 }
 
 // dW (Cout, Cin, 3, 3) (+)= the fold of dwb (4 Cout, Cin, 3, 3): the gradient of phase weight (ph, a) x (pw, b) -- stored at
@@ -2602,13 +2628,15 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
 extern "C" int mdm_upconv_pack(const float* w_oihw, void* w_ph, void* w_t, int Cout, int Cin, void* stream) {
   MDM_CHECK_ARG(w_oihw && w_ph && w_t && Cout % 64 == 0 && Cin % 64 == 0);
   hipLaunchKernelGGL(upconv_pack_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     w_oihw, (bf16*)w_ph, (bf16*)w_t, Cout, Cin);
+                     w_oihw, (bf16*)w_ph, Cout, Cin);
+  hipLaunchKernelGGL(upconv_pack_t_kernel, dim3((Cout / 64) * (Cin / 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     w_oihw, (bf16*)w_t, Cout, Cin);
   MDM_LAUNCH_STATUS();
 }
 // w (Cout, Cin, 3, 3) fp32 -> the bf16 pack mdm_conv_s2_dgrad reads
 extern "C" int mdm_s2dgrad_pack(const float* w_oihw, void* w_sel, int Cout, int Cin, void* stream) {
-  MDM_CHECK_ARG(w_oihw && w_sel && Cout % 64 == 0 && Cin > 0);
-  hipLaunchKernelGGL(s2dgrad_pack_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  MDM_CHECK_ARG(w_oihw && w_sel && Cout % 64 == 0 && Cin > 0 && Cin % 16 == 0);
+  hipLaunchKernelGGL(s2dgrad_pack_kernel, dim3((Cout / 64) * (Cin / 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      w_oihw, (bf16*)w_sel, Cout, Cin);
   MDM_LAUNCH_STATUS();
 }
