@@ -125,6 +125,10 @@ int mdm_conv_fwd_gn(const void* x, const void* w_packed, const float* bias, cons
                     int gn_act, void* y_norm, float* stats, float* coef, int dtype, void* stream);
 int mdm_conv_s2_dgrad(const void* dy, const void* w_sel, void* dx, int N, int Ho, int Wo, int Cout, int Cin, int dtype,
                       void* stream);
+/* the same + res [N, 2Ho, 2Wo, Cin] (or NULL) added to dx in the epilogue: the gradient of a skip connection that taps the
+ * tensor a down-sampling convolution reads (unet.py:566-567, 883-897), instead of a separate accumulation pass */
+int mdm_conv_s2_dgrad_res(const void* dy, const void* w_sel, const void* res, void* dx, int N, int Ho, int Wo, int Cout,
+                          int Cin, int dtype, void* stream);
 int mdm_s2dgrad_pack(const float* w_oihw, void* w_sel, int Cout, int Cin, void* stream);
 int mdm_upconv_pack(const float* w_oihw, void* w_ph, void* w_t, int Cout, int Cin, void* stream);
 int mdm_conv_up_fwd(const void* x, const void* w_ph, const float* bias4, void* y, int N, int H, int W, int Cin, int Cout,

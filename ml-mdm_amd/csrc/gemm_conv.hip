@@ -146,7 +146,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         const int row = idx / (BN / EPV), ch = idx - row * (BN / EPV);
         const int m = m0 + row, n = n0 + ch * EPV;
         pre[i] = uint4{0u, 0u, 0u, 0u};
-        if (m < p.M && n < p.Cout) pre[i] = *reinterpret_cast<const uint4*>(PSRC + (size_t)m * p.Cout + n);
+        if (m < p.M && n < p.Cout) {
+          size_t o = (size_t)m * p.Cout + n;
+          if (p.ps_cout > 0) {   // pixel-shuffled output: the residual has the OUTPUT's layout (same map as the store loop)
+            const int ph = n / p.ps_cout, co = n - ph * p.ps_cout;
+            const int bw = m % p.ps_W, t_ = m / p.ps_W;
+            const int bh = t_ % p.ps_H, img = t_ / p.ps_H;
+            o = (((size_t)img * (2 * p.ps_H) + 2 * bh + (ph >> 1)) * (2 * p.ps_W) + 2 * bw + (ph & 1)) * p.ps_cout + co;
+          }
+          pre[i] = *reinterpret_cast<const uint4*>(PSRC + o);
+        }
       }
     }
     __syncthreads();
@@ -2671,14 +2680,22 @@ static int launch_sel4(const ConvArgs& a, int tile, hipStream_t st) {
 //   dx[n, 2 bh + ph, 2 bw + pw, ci] = sum over (dh, dw) in {0, 1}^2, co of dy[n, bh + dh, bw + dw, co] * w_sel[(ph, pw, ci)][(dh, dw)][co]
 // w_sel: [4 Cin][Cout / 64][4 taps][64] (channel-block-major, tap j = 2 dh + dw), zero where the (phase, offset) pair has
 // no tap of the 3x3 kernel (7 of 16).  Cout % 64 == 0, Cin % 128 == 0.
+extern "C" int mdm_conv_s2_dgrad_res(const void* dy, const void* w_sel, const void* res, void* dx, int N, int Ho, int Wo,
+                                     int Cout, int Cin, int dtype, void* stream);
 extern "C" int mdm_conv_s2_dgrad(const void* dy, const void* w_sel, void* dx, int N, int Ho, int Wo, int Cout, int Cin,
                                  int dtype, void* stream) {
+  return mdm_conv_s2_dgrad_res(dy, w_sel, nullptr, dx, N, Ho, Wo, Cout, Cin, dtype, stream);
+}
+// ... + res [N, 2Ho, 2Wo, Cin] (or NULL): a second gradient of the same input -- the skip connection that taps the tensor a
+// down-sampling convolution reads (unet.py:566-567, 883-897) -- added in the epilogue instead of by a separate pass
+extern "C" int mdm_conv_s2_dgrad_res(const void* dy, const void* w_sel, const void* res, void* dx, int N, int Ho, int Wo,
+                                     int Cout, int Cin, int dtype, void* stream) {
   MDM_CHECK_ARG(dy && w_sel && dx && dtype == DT_BF16);
   MDM_CHECK_ARG(N > 0 && Ho > 0 && Wo > 0 && Cout % 64 == 0 && Cin > 0);
   const int tile = sel4_tile(Cin);
   MDM_CHECK_ARG(tile != 0);
   ConvArgs a = {};
-  a.x = dy; a.w = w_sel; a.y = dx;
+  a.x = dy; a.w = w_sel; a.y = dx; a.res = res;
   a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Ho = Ho; a.Wo = Wo; a.Cout = 4 * Cin; a.stride = 1;
   a.M = N * Ho * Wo; a.K = 4 * Cout; a.kblk = 64; a.ksplit = 1;
   a.sel_mode = 0; a.sel_base = 4;

@@ -663,7 +663,10 @@ class ConvFn(torch.autograd.Function):
     """y = conv(x, weight) + bias (+ residual).  3x3 (stride 1/2, pad 1), 1x1, or linear ([R, Cin])."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride):
+    def forward(ctx, x, weight, bias, residual, stride, tap=False):
+        """``tap``: also return x itself as a second output -- for a consumer that reads the same tensor (the skip
+        connection of a down-sampling block): its gradient comes back to ``backward`` and is added in the input
+        gradient's epilogue instead of by autograd's accumulation pass"""
         _require_gpu(x)
         x = _c(x)
         residual = _c(residual)
@@ -677,18 +680,25 @@ class ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, bias)
         ctx.stride, ctx.ks = stride, ks
         ctx.has_res = residual is not None
+        if tap:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dtap=None):
         x, weight, bias = ctx.saved_tensors
-        return _conv_backward(ctx, x, weight, bias, dy) + (None,)
+        if dy is None:
+            raise _lib.MdmHipError("conv(tap=True): the convolution's own output received no gradient")
+        return _conv_backward(ctx, x, weight, bias, dy, dtap) + (None, None)
 
 
-def _conv_backward(ctx, x, weight, bias, dy):
+def _conv_backward(ctx, x, weight, bias, dy, dtap=None):
     """input / weight / bias / residual gradients of y = conv(x, weight) + bias (+ residual); ``ctx`` carries ks, stride,
-    has_res and needs_input_grad[0:4] = (x, weight, bias, residual).  -> (dx, dw, db, dres)"""
+    has_res and needs_input_grad[0:4] = (x, weight, bias, residual); ``dtap``: a second gradient of x, added to dx.
+    -> (dx, dw, db, dres)"""
     dy = _c(dy)
+    dtap = _c(dtap)
     ks, stride = ctx.ks, ctx.stride
     wf, wd, bp, cin_pad, cout_pad, kbf, kbd = packed_weight(weight, bias, x.dtype)
     cout, cin = weight.shape[0], weight.shape[1]
@@ -704,12 +714,17 @@ def _conv_backward(ctx, x, weight, bias, dy):
             wsel = packed_s2_dgrad_weight(weight)
             _prof_wrap("conv_gemm_bl_kernel<sel4> (3x3 stride-2 input gradient) M=%d N=%d K=%d" % (N * Ho * Wo, 4 * cin, 4 * cout),
                        2.0 * N * Ho * Wo * cout * 9 * cin, lambda: _lib.check(
-                _lib.lib().mdm_conv_s2_dgrad(_p(dy), _p(wsel), _p(dx), N, Ho, Wo, cout, cin, BF16, _stream()), "mdm_conv_s2_dgrad"),
-                       executed=2.0 * N * Ho * Wo * (4 * cin) * (4 * cout))
+                _lib.lib().mdm_conv_s2_dgrad_res(_p(dy), _p(wsel), _p(dtap), _p(dx), N, Ho, Wo, cout, cin, BF16, _stream()),
+                "mdm_conv_s2_dgrad_res"), executed=2.0 * N * Ho * Wo * (4 * cin) * (4 * cout))
+            dtap = None
         elif ks == 3 and stride == 2:
             _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, 3, 1, 1, 0, kbd)
         else:
             _conv_launch(dy, wd, None, None, None, dx, None, N, Ho, Wo, cout_pad, H, W, cin, ks, 1, 0, 0, kbd)
+        if dtap is not None:   # shapes the sub-pixel kernel does not take
+            dx = dx + dtap
+    elif dtap is not None:
+        dx = dtap
     padded = cout_pad != cout or cin_pad != cin
     want_b = bias is not None and ctx.needs_input_grad[2]
     if ctx.needs_input_grad[1]:
@@ -742,6 +757,14 @@ def _conv_backward(ctx, x, weight, bias, dy):
 
 def conv(x, weight, bias=None, residual=None, stride=1):
     return ConvFn.apply(x, weight, bias, residual, stride)
+
+
+def conv_tap(x, weight, bias=None, stride=1):
+    """(conv(x), x'): x' is x for a second consumer whose gradient is then added inside the convolution's input-gradient
+    kernel (mdm_conv_s2_dgrad_res for the stride-2 3x3 case) rather than by a separate accumulation pass"""
+    if not (torch.is_grad_enabled() and x.requires_grad) or os.environ.get("MDM_HIP_NO_CONV_TAP", "0") == "1":
+        return ConvFn.apply(x, weight, bias, None, stride), x
+    return ConvFn.apply(x, weight, bias, None, stride, True)
 
 
 # --------------------------------------------------------------------------------------

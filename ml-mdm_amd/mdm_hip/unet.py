@@ -292,7 +292,11 @@ class ResNetBlock(nn.Module):
             if skip_activations is None:
                 tap = (activations, len(activations) - 1)   # the next ResNet of this block reads the x recorded here
         if self.downsample_output:
-            x = ops.conv(x, self.resample.weight, self.resample.bias, stride=2)
+            if activations and activations[-1] is x:
+                # x also feeds a skip connection (reference unet.py:566-567): that gradient joins the convolution's own
+                x, activations[-1] = ops.conv_tap(x, self.resample.weight, self.resample.bias, stride=2)
+            else:
+                x = ops.conv(x, self.resample.weight, self.resample.bias, stride=2)
             activations.append(x)
         elif self.upsample_output:
             x = ops.upsample_conv(x, self.resample.weight, self.resample.bias)

@@ -112,6 +112,47 @@ def test_conv_fwd_bwd(dtype, N, H, W, Cin, Cout, ks, stride):
     assert relerr(nchw(rd.grad), res.grad) < tol
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize(
+    "N,H,W,Cin,Cout",
+    [
+        (2, 32, 32, 256, 256),     # bf16: the sub-pixel input gradient adds the tap's gradient in its epilogue
+        (4, 64, 48, 128, 192),     # same, ragged tiles
+        (2, 16, 16, 64, 64),       # shapes that kernel does not take: the generic input gradient + one add
+    ],
+)
+def test_conv_tap_joins_the_skip_gradient(dtype, N, H, W, Cin, Cout):
+    """ops.conv_tap: y = conv(x) (3x3, stride 2) and a second reader of x (the skip connection of a down-sampling block,
+    reference unet.py:566-567); dL/dx = conv input gradient + the second reader's gradient, from one kernel"""
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = q(torch.randn(N, Cin, H, W, generator=g), dtype).requires_grad_()
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9), dtype).requires_grad_()
+    b = torch.randn(Cout, generator=g).requires_grad_()
+    y_ref = F.conv2d(x, w, b, stride=2, padding=1)
+    gy = q(torch.randn(y_ref.shape, generator=g), dtype)
+    gs = q(torch.randn(x.shape, generator=g), dtype)
+    torch.autograd.backward([y_ref, x * 1.0], [gy, gs])
+
+    xd = nhwc(x.detach(), dtype).requires_grad_()
+    wd = w.detach().to(dev()).requires_grad_()
+    bd = b.detach().to(dev()).requires_grad_()
+    h = xd * 1.0     # a non-leaf input, as in the model
+    y, skip = ops.conv_tap(h, wd, bd, stride=2)
+    assert skip.data_ptr() == h.data_ptr()
+    torch.autograd.backward([y, skip], [nhwc(gy, dtype), nhwc(gs, dtype)])
+    tol = TOL[dtype]
+    assert relerr(nchw(y), y_ref) < tol
+    assert relerr(nchw(xd.grad), x.grad) < tol
+    assert relerr(wd.grad, w.grad) < tol
+    assert relerr(bd.grad, b.grad) < tol
+    # only the tap is read: the convolution's own output must still have received a gradient
+    y2, skip2 = ops.conv_tap(nhwc(x.detach(), dtype).requires_grad_(), wd, bd, stride=2)
+    with pytest.raises(Exception):
+        skip2.sum().backward()
+
+
 @pytest.mark.parametrize("N,H,W,Cin,ks", [(4, 256, 256, 64, 3), (2, 264, 512, 64, 3)])
 def test_conv_wgrad_direct_kernel(N, H, W, Cin, ks):
     """The narrow weight gradients of the nested models' outer levels (64 output channels, a million pixels): the direct
