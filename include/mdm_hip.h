@@ -19,6 +19,9 @@
  *                    as three bf16 MFMAs on bf16 hi + lo halves of the fp32 operands (x*y to ~2^-16 relative): the
  *                    reference samples in fp32 (diffusion.py:181-197, clis/generate_sample.py:230-256); this is that
  *                    precision class (1e-3 sampling gate) at about a third of the bf16 rate instead of 1/16
+ *       MDM_F32_SPLIT_W (3; mdm_conv_fwd, mdm_conv_fwd_ws only) the same arithmetic, bit for bit, with w_packed already
+ *                    split into hi / lo planes by mdm_split_weight_planes (weights are constant over the 50-250 denoise
+ *                    iterations of a sampling run: half the conversion work leaves the k-loop); needs k*k*Cin % 8 == 0
  *     parameters, their gradients, normalisation statistics and LSEs are always fp32
  *   - activations are NHWC: [N, H, W, C] (a linear layer is N=rows, H=W=1)
  *   - channel counts must be multiples of the 16-byte chunk: 4 (fp32) / 8 (bf16)
@@ -41,7 +44,7 @@
 extern "C" {
 #endif
 
-enum { MDM_F32 = 0, MDM_BF16 = 1 };
+enum { MDM_F32 = 0, MDM_BF16 = 1, MDM_F32_SPLIT = 2, MDM_F32_SPLIT_W = 3 };
 enum { MDM_ACT_NONE = 0, MDM_ACT_GELU = 1, MDM_ACT_DGELU_AUX = 2 };
 
 int mdm_abi_version(void);
@@ -77,6 +80,11 @@ const char* mdm_last_error(void);
  */
 int mdm_pack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int ksize, int Cin_pad,
                     int Cout_pad, int kblock_fwd, int kblock_dgrad, int dtype, void* stream);
+/* planes for MDM_F32_SPLIT_W: the n fp32 values (n % 8 == 0) of a packed weight (either output of mdm_pack_weight with
+ * dtype MDM_F32) -> `planes` (4 n bytes, a different buffer): run r of 8 values becomes [8 bf16 hi | 8 bf16 lo],
+ * hi = bf16(v), lo = bf16(v - hi) -- the split the MDM_F32_SPLIT k-loop performs on the fly (no reference counterpart: the
+ * reference samples in plain fp32, diffusion.py:181-197) */
+int mdm_split_weight_planes(const float* w_packed, void* planes, size_t n, void* stream);
 /* every kernel-layout weight of a model in ONE launch (they all go stale at each optimizer step).  `table`: DEVICE
  * array of n 48-byte descriptors {const float* w; void* w_fwd; void* w_dgrad (or NULL); int Cout, Cin, taps (1 | 9),
  * kblock_fwd, kblock_dgrad, first_block}; first_block = running sum of (Cout/32)*(Cin/32); total_blocks = the final

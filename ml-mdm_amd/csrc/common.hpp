@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // DT_F32_SPLIT: fp32 tensors and accumulators, the products formed as three bf16 MFMAs (x = hi + lo, both bf16:
 // x*y ~ hi*hi' + hi*lo' + lo*hi') -- the arithmetic of the "fp32 at a third of the bf16 rate" sampling mode.  Accepted
 // where a kernel has the path (mdm_conv_fwd*, mdm_attn_fwd); everything else takes DT_F32 for the same tensors.
-enum { DT_F32 = 0, DT_BF16 = 1, DT_F32_SPLIT = 2 };
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F32_SPLIT = 2, DT_F32_SPLIT_W = 3 };   // _W: + the weight operand pre-split into planes
 
 template <typename T> struct Tr;
 template <> struct Tr<float> {

@@ -373,9 +373,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
   }
 }
 
+// B operand of the bf16x3 form when the weights were split into planes ahead of time (mdm_split_weight_planes: every run of
+// 8 fp32 values = 32 bytes holds [8 bf16 hi | 8 bf16 lo]): the two 16-byte chunks a lane reads ARE its hi and lo fragments
+__device__ __forceinline__ void load_frag_planes(FragSplit& f, const char* t, int row, int quad) {
+  f.hi = *reinterpret_cast<const bf16x8*>(t + lds_chunk_off(row, 2 * quad));
+  f.lo = *reinterpret_cast<const bf16x8*>(t + lds_chunk_off(row, 2 * quad + 1));
+}
+template <typename F> __device__ __forceinline__ void load_frag_planes(F&, const char*, int, int) {}
+
 // Double-buffered: the next tile's LDS-DMA overlaps this tile's MFMAs; __syncthreads() drains it (vmcnt(0)).
-// SPLIT (float only): the products as three bf16 MFMAs on hi / lo halves of the fp32 operands (common.hpp FragSplit)
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool SPLIT = false>
+// SPLIT (float only): 1 = the products as three bf16 MFMAs on hi / lo halves of the fp32 operands (common.hpp FragSplit),
+// both operands split in the loop; 2 = the same with the weight operand already stored as hi / lo planes (half the
+// conversion work of the loop: 97.8 -> 88.9 ms per iteration of the 64x64 sampler at batch 64, eager)
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int SPLIT = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(ConvArgs p) {
   constexpr int NSTAGE = 2;
   constexpr int EPV = Tr<T>::EPV, BK = Tr<T>::BK, KSTEPS = Tr<T>::KSTEPS;
@@ -488,9 +498,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(ConvArgs p) 
     const char* As = (cur);                                                                               \
     const char* Bs = (cur) + A_BYTES;                                                                     \
     _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                               \
-      typename FragOf<T, SPLIT>::type af[MT], bfr[NT];                                                    \
+      typename FragOf<T, SPLIT != 0>::type af[MT], bfr[NT];                                               \
       _Pragma("unroll") for (int i = 0; i < MT; ++i) load_frag_x(af[i], As, wm * TM + i * 16 + l16, ks, quad);    \
-      _Pragma("unroll") for (int j = 0; j < NT; ++j) load_frag_x(bfr[j], Bs, wn * TN + j * 16 + l16, ks, quad);   \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                    \
+        if constexpr (SPLIT == 2) load_frag_planes(bfr[j], Bs, wn * TN + j * 16 + l16, quad);             \
+        else load_frag_x(bfr[j], Bs, wn * TN + j * 16 + l16, ks, quad);                                   \
+      }                                                                                                   \
       _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                      \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) mma16(acc[i][j], bfr[j], af[i]);                   \
     }                                                                                                     \
@@ -2208,7 +2221,7 @@ static inline ConvArgs with_dev_flags(const ConvArgs& a) { ConvArgs b = a; b.dev
 static thread_local char g_last_gemm[96] = "";
 extern "C" const char* mdm_last_gemm_kernel(void) { return g_last_gemm; }
 #define MDM_NOTE_KERNEL(...) snprintf(g_last_gemm, sizeof(g_last_gemm), __VA_ARGS__)
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool SPLIT = false>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int SPLIT = 0>
 static int launch_conv_cfg(const ConvArgs& a_, hipStream_t st) {
   const ConvArgs a = with_dev_flags(a_);
   constexpr int smem = 2 * (BM + BN) * 128;
@@ -2216,7 +2229,7 @@ static int launch_conv_cfg(const ConvArgs& a_, hipStream_t st) {
   ensure_dynamic_lds(kern, smem);
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), smem, st, a);
-  MDM_NOTE_KERNEL("conv_gemm_kernel<%s, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : (SPLIT ? "float (bf16x3)" : "float"), BM, BN, WM, WN, MODE);
+  MDM_NOTE_KERNEL("conv_gemm_kernel<%s, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : (SPLIT == 2 ? "float (bf16x3, weight planes)" : (SPLIT ? "float (bf16x3)" : "float")), BM, BN, WM, WN, MODE);
   MDM_LAUNCH_STATUS();
 }
 
@@ -2557,7 +2570,7 @@ static int launch_conv_direct_any(const ConvArgs& a, hipStream_t st) {
   return launch_conv_direct<64, 64, 8, 32, 4>(a, st);
 }
 
-template <typename T, int MODE, bool SPLIT = false>
+template <typename T, int MODE, int SPLIT = 0>
 static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv_cfg<T, 128, 32, 4, 1, MODE, SPLIT>(a, st);
   if (a.Cout <= 64) return launch_conv_cfg<T, 128, 64, 2, 2, MODE, SPLIT>(a, st);
@@ -2573,10 +2586,12 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
     // problems the buffer-addressed loader cannot express (ragged K, transposed stride-2 gradient, > 2 GiB operands)
     if (code != 128128) return launch_conv_cfg<T, 256, 256, 2, 4, MODE>(a, st);
   }
+  // (weight planes with 4 x 1 waves -- a wave splits 2 activation fragments per k-step instead of 4, and reads 8 weight
+  // fragments instead of 4 -- measured 88.3 against 88.7 ms per iteration: profiles/r06_did_not_pay.md)
   return launch_conv_cfg<T, 128, 128, 2, 2, MODE, SPLIT>(a, st);
 }
 
-template <typename T, bool SPLIT = false>
+template <typename T, int SPLIT = 0>
 static int launch_conv_t(const ConvArgs& a, int ks, int transposed, hipStream_t st) {
   if (ks == 1) return launch_conv_mode<T, MODE_1x1, SPLIT>(a, st);
   if (transposed) return launch_conv_mode<T, MODE_3x3_T2, SPLIT>(a, st);
@@ -2591,9 +2606,11 @@ extern "C" int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float*
                                float* ws, size_t ws_bytes, void* stream) {
   MDM_CHECK_ARG(x && w_packed && y);
   MDM_CHECK_ARG(ksize == 1 || ksize == 3);
-  MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16 || dtype == DT_F32_SPLIT);
-  const bool split_products = dtype == DT_F32_SPLIT;   // fp32 tensors, bf16x3 products (include/mdm_hip.h MDM_DT_F32_SPLIT)
+  MDM_CHECK_ARG(dtype == DT_F32 || dtype == DT_BF16 || dtype == DT_F32_SPLIT || dtype == DT_F32_SPLIT_W);
+  // fp32 tensors, bf16x3 products (include/mdm_hip.h MDM_F32_SPLIT; _W: w_packed went through mdm_split_weight_planes)
+  const int split_products = dtype == DT_F32_SPLIT ? 1 : (dtype == DT_F32_SPLIT_W ? 2 : 0);
   if (split_products) dtype = DT_F32;
+  MDM_CHECK_ARG(split_products != 2 || (ksize * ksize * Cin) % 8 == 0);   // planes are runs of 8 along the reduction
   MDM_CHECK_ARG(act >= 0 && act <= 2);
   MDM_CHECK_ARG(act != 2 || aux);
   MDM_CHECK_ARG(!(act == 2 && res));   // one elementwise operand per launch (conv_epilogue keeps loads out of its store loop)
@@ -2620,7 +2637,8 @@ extern "C" int mdm_conv_fwd_ws(const void* x, const void* w_packed, const float*
       if (ksize == 3 && conv_bl_ok<bf16, MODE_3x3>(a)) return launch_conv_bl_splitk<MODE_3x3>(a, sp, ws, st);
     }
   }
-  if (split_products) return launch_conv_t<float, true>(a, ksize, transposed, st);
+  if (split_products == 2) return launch_conv_t<float, 2>(a, ksize, transposed, st);
+  if (split_products) return launch_conv_t<float, 1>(a, ksize, transposed, st);
   return dtype == DT_F32 ? launch_conv_t<float>(a, ksize, transposed, st) : launch_conv_t<bf16>(a, ksize, transposed, st);
 }
 
@@ -2632,6 +2650,24 @@ extern "C" int mdm_conv_fwd(const void* x, const void* w_packed, const float* bi
                          kblock, dtype, nullptr, 0, stream);
 }
 
+
+// n fp32 values of a packed weight (n % 8 == 0) -> the same bytes as hi / lo bf16 planes: run r of 8 values becomes
+// [bf16 hi(v0..v7) | bf16 lo(v0..v7)], lo = bf16(v - float(hi)) -- what FragSplit::from_f32 computes in the k-loop
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ w, uint4* __restrict__ out, size_t runs) {
+  const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= runs) return;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(w + r * 8), b = *reinterpret_cast<const f32x4*>(w + r * 8 + 4);
+  FragSplit f;
+  f.from_f32(a, b);
+  out[2 * r] = *reinterpret_cast<const uint4*>(&f.hi);
+  out[2 * r + 1] = *reinterpret_cast<const uint4*>(&f.lo);
+}
+extern "C" int mdm_split_weight_planes(const float* w_packed, void* planes, size_t n, void* stream) {
+  MDM_CHECK_ARG(w_packed && planes && w_packed != planes && n > 0 && n % 8 == 0);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     w_packed, (uint4*)planes, n / 8);
+  MDM_LAUNCH_STATUS();
+}
 
 // w (Cout, Cin, 3, 3) fp32 -> the two bf16 packs of the sub-pixel upsample convolution (mdm_conv_up_fwd / _dgrad)
 extern "C" int mdm_upconv_pack(const float* w_oihw, void* w_ph, void* w_t, int Cout, int Cin, void* stream) {

@@ -16,12 +16,13 @@ import torch
 
 from . import _lib
 
-F32, BF16, F32_SPLIT = 0, 1, 2
+F32, BF16, F32_SPLIT, F32_SPLIT_W = 0, 1, 2, 3
 
 # fp32 tensors, products as three bf16 MFMAs on bf16 hi + lo halves (include/mdm_hip.h MDM_F32_SPLIT): the arithmetic of
 # sampling at the reference's precision (it samples in fp32, diffusion.py:181-197) at about a third of the bf16 rate.  Only
 # the forward matmul-class launches have the path (convolutions / linears, attention); training in fp32 stays exact.
 _fp32_split = False
+_weight_planes_on = os.environ.get("MDM_HIP_NO_WEIGHT_PLANES", "0") != "1"   # development A/B: split the weights in the k-loop too
 
 
 class fp32_split:
@@ -414,6 +415,7 @@ def packed_weight(weight: torch.Tensor, bias, dtype: torch.dtype):
                           F32 if dtype == torch.float32 else BF16, _stream()),
         "mdm_pack_weight",
     )
+    _repacked(wf, wd)
     bp = None
     if bias is not None:
         bp = bias.detach().float()
@@ -487,6 +489,7 @@ def repack_all(dtype: torch.dtype):
                "mdm_pack_weights_multi")
     for w, ent, ver, val, *_ in items:
         ent[dtype] = ((w._version, ver[1], w.data_ptr(), _pack_epoch), val)
+        _repacked(val[0], val[1])
 
 
 # --------------------------------------------------------------------------------------
@@ -579,15 +582,38 @@ def _conv_plan(M, Cout, K, dt):
     return ent
 
 
+def _repacked(*packs):
+    """note that these kernel-layout weights were (re-)written: planes made from them are stale"""
+    for t in packs:
+        if t is not None:
+            t._mdm_serial = getattr(t, "_mdm_serial", 0) + 1
+
+
+def _weight_planes(w: torch.Tensor):
+    """The packed fp32 weight ``w`` as bf16 hi / lo planes (C ABI mdm_split_weight_planes), cached on the packed tensor
+    until it is re-packed: under MDM_F32_SPLIT the weight operand's split leaves the k-loop (97.8 -> 88.9 ms per
+    iteration of the 64x64 sampler at batch 64; the products are bit-identical)."""
+    ent, serial = getattr(w, "_mdm_planes", None), getattr(w, "_mdm_serial", 0)
+    if ent is not None and ent[0] == serial:
+        return ent[1]
+    planes = torch.empty_like(w)
+    _lib.check(_lib.lib().mdm_split_weight_planes(_p(w), _p(planes), w.numel(), _stream()), "mdm_split_weight_planes")
+    w._mdm_planes = (serial, planes)
+    return planes
+
+
 def _conv_launch(x, w, bias, res, aux, y, ypre, N, H, W, Cin, Ho, Wo, Cout, ks, stride, transposed, act, kblk=0):
     # problems too small to fill the chip with output tiles (sampling at batch 1-4) run split over the reduction
     splits, wsb = _conv_plan(N * Ho * Wo, Cout, ks * ks * Cin, _dt(x)) if (stride == 1 and not transposed) else (1, 0)
     ws = _f32_ws(wsb, x.device) if splits > 1 else None
+    dt = _dt_mm(x)
+    if dt == F32_SPLIT and (ks * ks * Cin) % 8 == 0 and w.numel() % 8 == 0 and _weight_planes_on:
+        w, dt = _weight_planes(w), F32_SPLIT_W
 
     def go():
         _lib.check(
             _lib.lib().mdm_conv_fwd_ws(_p(x), _p(w), _p(bias), _p(res), _p(aux), _p(y), _p(ypre), N, H, W, Cin, Ho, Wo, Cout,
-                                       ks, stride, transposed, act, kblk, _dt_mm(x), _p(ws), wsb, _stream()),
+                                       ks, stride, transposed, act, kblk, dt, _p(ws), wsb, _stream()),
             "mdm_conv_fwd",
         )
 

@@ -204,12 +204,56 @@ def test_conv_fp32_split_products(N, H, W, Cin, Cout, ks, stride):
         y = ops.conv(nhwc(x, torch.float32), w.to(dev()), b.to(dev()), residual=nhwc(res, torch.float32), stride=stride)
         torch.cuda.synchronize()
         assert "bf16x3" in _lib.lib().mdm_last_gemm_kernel().decode()
+        # the weight operand came in as hi / lo planes made ahead of time (MDM_F32_SPLIT_W); splitting it inside the k-loop
+        # (MDM_F32_SPLIT) gives the same bits
+        assert "weight planes" in _lib.lib().mdm_last_gemm_kernel().decode()
+        ops._weight_planes_on = False
+        try:
+            y_loop = ops.conv(nhwc(x, torch.float32), w.to(dev()), b.to(dev()), residual=nhwc(res, torch.float32), stride=stride)
+            torch.cuda.synchronize()
+            name = _lib.lib().mdm_last_gemm_kernel().decode()
+            assert "bf16x3" in name and "weight planes" not in name
+        finally:
+            ops._weight_planes_on = True
+        assert torch.equal(y, y_loop)
     err = relerr(nchw(y), y_ref)
     assert err < 2e-4, err
     with torch.no_grad():   # and the switch is off again: the exact path
         y2 = ops.conv(nhwc(x, torch.float32), w.to(dev()), b.to(dev()), residual=nhwc(res, torch.float32), stride=stride)
         assert "bf16x3" not in _lib.lib().mdm_last_gemm_kernel().decode()
     assert relerr(nchw(y2), y_ref) < TOL[torch.float32]
+
+
+def test_weight_planes_follow_a_repack():
+    """the planes are cached on the packed weight and rebuilt when it is re-packed (a parameter update)"""
+    from mdm_hip import ops
+
+    g = torch.Generator().manual_seed(6)
+    x = nhwc(torch.randn(2, 64, 8, 8, generator=g), torch.float32)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(dev())
+    with torch.no_grad(), ops.fp32_split():
+        y1 = ops.conv(x, w)
+        y1b = ops.conv(x, w)
+        w.mul_(2.0)
+        y2 = ops.conv(x, w)
+    assert torch.equal(y1, y1b)
+    assert relerr(y2, 2 * y1) < 1e-6
+
+
+def test_split_weight_planes_argument_checks():
+    from mdm_hip import _lib
+
+    L = _lib.lib()
+    a = torch.zeros(64, device=dev())
+    b = torch.zeros(64, device=dev())
+    assert L.mdm_split_weight_planes(a.data_ptr(), b.data_ptr(), 60, None) < 0      # not whole runs of 8
+    assert L.mdm_split_weight_planes(a.data_ptr(), a.data_ptr(), 64, None) < 0      # in place
+    assert L.mdm_split_weight_planes(a.data_ptr(), b.data_ptr(), 64, None) == 0
+    # MDM_F32_SPLIT_W with a reduction that is not a multiple of 8 (1x1, Cin = 4)
+    x = torch.zeros(1, 2, 2, 4, device=dev()); y = torch.zeros(1, 2, 2, 8, device=dev()); w = torch.zeros(32, device=dev())
+    assert L.mdm_conv_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), None, 1, 2, 2, 4, 2, 2, 8, 1, 1, 0, 0, 0, 3, None) < 0
+    assert L.mdm_conv_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), None, 1, 2, 2, 4, 2, 2, 8, 1, 1, 0, 0, 0, 2, None) == 0
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("B,L,S,H,d,masked", [(2, 256, 32, 4, 96, True), (1, 1024, 32, 2, 64, False), (3, 64, 0, 2, 32, False)])
