@@ -1271,6 +1271,8 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   // per MFMA that 32 queries per wave save.
   if constexpr (sizeof(T) == 2 && !SPLIT) {
     const long blocks2 = (long)((a.L + 127) / 128) * a.B * a.H;
+    // (not for a training batch at L = 256: 58 against 47-52 us at d = 96, batch 64 -- three blocks per CU instead of two do
+    //  not make up for one MFMA per K / V fragment read; profiles/r06_did_not_pay.md)
     if (blocks2 * 2 <= device_cus() && a.L > 64) {
       ensure_dynamic_lds(attn_fwd_kernel<T, D, 1, true, SPLIT>, smem);
       dim3 grid1((a.L + 63) / 64, a.B * a.H);
