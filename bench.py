@@ -267,8 +267,15 @@ def main():
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
         dist.init_process_group(backend=os.environ.get("MDM_DIST_BACKEND", "nccl"), init_method="env://", world_size=1, rank=0)
-    # MDM_DIST_BACKEND=gloo + MDM_BENCH_DEVICE=0 let two ranks share ONE GPU (development check of the N > 1 path
-    # on the single-GPU box); the driver's real runs use RCCL with one GPU per rank
+    # MDM_BENCH_DEVICE=0 lets two ranks share ONE GPU (development check of the N > 1 path on the single-GPU box; timing
+    # meaningless); the driver's real runs use RCCL with one GPU per rank.  With MDM_DIST_BACKEND=gloo the wire is gloo; with
+    # RCCL each rank claims its own host id -- RCCL refuses two ranks of one host on one device, and then talks over the
+    # socket transport on loopback (the recipe of tests/test_distributed_gpu.py::test_two_rank_train_step_over_rccl)
+    if "MDM_BENCH_DEVICE" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("MDM_DIST_BACKEND", "nccl") == "nccl":
+        os.environ.setdefault("NCCL_HOSTID", "mdm-bench-rank-%s" % os.environ.get("RANK", "0"))
+        os.environ["LOCAL_RANK"] = os.environ["MDM_BENCH_DEVICE"]
+        for k, v in (("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1"), ("NCCL_P2P_DISABLE", "1"), ("NCCL_SHM_DISABLE", "1")):
+            os.environ.setdefault(k, v)
     local, rank, world = mdist.init_distributed_singlenode(backend=os.environ.get("MDM_DIST_BACKEND"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     if "MDM_BENCH_DEVICE" in os.environ:
