@@ -57,6 +57,9 @@ def timeit(fn, iters=10):
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if os.environ.get("KB_TILE"):   # force the forward / input-gradient tile: 128128 / 256192 / 256256 (development knob 2)
+        from mdm_hip import _lib
+        _lib.lib().mdm_dev_set_knob(2, int(os.environ["KB_TILE"]))
     only = os.environ.get("KB_ONLY")
     for idx, (name, H, cin, cout, ks, stride) in enumerate(SHAPES):
         if only is not None and idx != int(only):
