@@ -172,6 +172,9 @@ def join_side_stream():
     _side_keep.clear()   # every later main-stream write is ordered behind the side stream's reads now
 
 
+_side_record_stream = os.environ.get("MDM_HIP_RECORD_STREAM", "0") == "1"   # development A/B: the old belt-and-braces form
+
+
 def _off_critical_path(tensors, fn):
     """run fn() (kernel launches that only write gradient-arena slots) on the side stream when enabled"""
     if not (_async_wgrad and _grad_sink is not None):
@@ -182,9 +185,16 @@ def _off_critical_path(tensors, fn):
         fn()
         done = torch.cuda.Event()
         done.record(side)
+    # The operands stay referenced here until the side stream has passed `done` (the purge below) or the main stream has been
+    # made to wait for the side stream (join_side_stream): their blocks cannot be handed out again before that, so no
+    # Tensor.record_stream is needed.  (Rounds 2-6 called it as well: the caching allocator then records one event per block
+    # on the side stream when the block is freed -- a purge of 64 entries freed ~330 blocks at once, 0.5-1.3 ms of
+    # hipEventRecord calls on the host, and the one at the end of backward, where the host has no lead left, showed up as a
+    # gap of that length with the whole GPU idle: tools/fwd_gaps.py --gaps, tools/calls/r6/c39_hip_trace.sh.)
     live = [t for t in tensors if t is not None]
-    for t in live:
-        t.record_stream(side)
+    if _side_record_stream:
+        for t in live:
+            t.record_stream(side)
     _side_keep.append((done, live))
     if len(_side_keep) >= 64:
         _side_keep[:] = [e for e in _side_keep if not e[0].query()]

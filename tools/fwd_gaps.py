@@ -32,4 +32,23 @@ for a, b in zip(packs[:-1], packs[1:]):
         busy += cur_e - cur_s
         print("%-13s %4d kernels  wall %7.2f ms  sum of kernel durations %7.2f ms  GPU busy (union) %7.2f ms  idle %5.2f ms" % (
             tag, len(part), wall, ksum, busy / 1e6, wall - busy / 1e6))
+        if "--gaps" in sys.argv and tag != "forward":
+            # the largest intervals in which NO stream runs a kernel, with the kernel that ended before and the one that began after
+            ev = sorted(part, key=lambda r: r[1])
+            gaps, end, last = [], ev[0][2], ev[0]
+            for r in ev[1:]:
+                if r[1] > end:
+                    gaps.append((r[1] - end, (end - part[0][1]) / 1e6, last[0][:60], r[0][:60]))
+                if r[2] > end:
+                    end, last = r[2], r
+            gaps.sort(reverse=True)
+            for g in gaps[:8]:
+                print("      gap %6.1f us at %6.2f ms   after %-60s before %s" % (g[0] / 1e3, g[1], g[2], g[3]))
+            print("      %d gaps, %.2f ms in gaps below 20 us" % (len(gaps), sum(g[0] for g in gaps if g[0] < 20e3) / 1e6))
+            if "--around" in sys.argv and gaps:
+                # the launches either side of the largest gap: start (ms into the window), duration (us), stream, name
+                t_gap = gaps[0][1] * 1e6 + part[0][1]
+                near = [r for r in ev if r[2] > t_gap - 1.0e6 and r[1] < t_gap + 4.5e6]
+                for r in near:
+                    print("        %8.3f ms %7.1f us  q%-3s %s" % ((r[1] - part[0][1]) / 1e6, (r[2] - r[1]) / 1e3, r[3] if len(r) > 3 else "?", r[0][:90]))
     print()
