@@ -72,8 +72,33 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# The current stream's raw handle.  torch.cuda.current_stream() builds a Stream object through four Python layers (device
+# index lookups, is_available(), an environment read): ~5 us a call, ~1100 calls per nested-256 train step -- a sixth of the
+# host's time per step in a profile (tools/host_profile.py), on a step whose small inner-U-Net kernels leave the host little
+# lead.  The C entry point behind it returns the same handle in ~0.2 us.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+if os.environ.get("MDM_HIP_SLOW_STREAM_LOOKUP", "0") == "1":   # development A/B
+    _raw_stream = None
+
+
 def _stream():
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+_stream_objs = {}   # raw handle -> torch Stream object of a stream that has been current (torch never destroys its streams)
+
+
+def _current_stream_obj():
+    raw = _stream()
+    st = _stream_objs.get(raw)
+    if st is None:
+        if len(_stream_objs) > 64:
+            _stream_objs.clear()
+        st = _stream_objs[raw] = torch.cuda.current_stream()
+    return st
 
 
 def _require_gpu(t: torch.Tensor):
@@ -180,11 +205,23 @@ def _off_critical_path(tensors, fn):
     if not (_async_wgrad and _grad_sink is not None):
         return fn()
     side = side_stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        fn()
-        done = torch.cuda.Event()
-        done.record(side)
+    if _raw_stream is None:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            done = torch.cuda.Event()
+            done.record(side)
+    else:
+        # the same, without the Python layers of current_stream() / the StreamContext (this runs ~120 times per step)
+        cur = _current_stream_obj()
+        side.wait_stream(cur)
+        torch.cuda.set_stream(side)
+        try:
+            fn()
+            done = torch.cuda.Event()
+            done.record(side)
+        finally:
+            torch.cuda.set_stream(cur)
     # The operands stay referenced here until the side stream has passed `done` (the purge below) or the main stream has been
     # made to wait for the side stream (join_side_stream): their blocks cannot be handed out again before that, so no
     # Tensor.record_stream is needed.  (Rounds 2-6 called it as well: the caching allocator then records one event per block
