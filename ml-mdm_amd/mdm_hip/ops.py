@@ -226,8 +226,9 @@ def _off_critical_path(tensors, fn):
     # made to wait for the side stream (join_side_stream): their blocks cannot be handed out again before that, so no
     # Tensor.record_stream is needed.  (Rounds 2-6 called it as well: the caching allocator then records one event per block
     # on the side stream when the block is freed -- a purge of 64 entries freed ~330 blocks at once, 0.5-1.3 ms of
-    # hipEventRecord calls on the host, and the one at the end of backward, where the host has no lead left, showed up as a
-    # gap of that length with the whole GPU idle: tools/fwd_gaps.py --gaps, tools/calls/r6/c39_hip_trace.sh.)
+    # hipEventRecord calls = as many marker packets in the side stream's queue, and at the end of backward, where the main
+    # stream waits for the side stream, a gap of that length with the whole GPU idle: tools/fwd_gaps.py --gaps,
+    # tools/calls/r6/c39_hip_trace.sh; the host itself is 57-117 ms ahead, profiles/r06_host_lead.txt.)
     live = [t for t in tensors if t is not None]
     if _side_record_stream:
         for t in live:
