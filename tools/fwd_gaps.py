@@ -45,6 +45,18 @@ for a, b in zip(packs[:-1], packs[1:]):
             for g in gaps[:8]:
                 print("      gap %6.1f us at %6.2f ms   after %-60s before %s" % (g[0] / 1e3, g[1], g[2], g[3]))
             print("      %d gaps, %.2f ms in gaps below 20 us" % (len(gaps), sum(g[0] for g in gaps if g[0] < 20e3) / 1e6))
+            if qcol:
+                # bubbles on each queue alone: between consecutive kernels of the SAME queue (the main stream is the critical
+                # path of backward; a bubble there costs step time even while the other stream keeps the GPU busy)
+                byq = {}
+                for r in ev:
+                    byq.setdefault(r[3], []).append(r)
+                for qid, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
+                    gs = [b[1] - a[2] for a, b in zip(rs[:-1], rs[1:]) if b[1] > a[2]]
+                    small = [g for g in gs if g < 30e3]
+                    print("      queue %-4s %4d kernels  busy %6.2f ms  gaps below 30 us: %4d, %.2f ms (median %.1f us); larger: %d, %.2f ms" % (
+                        qid, len(rs), sum(r[2] - r[1] for r in rs) / 1e6, len(small), sum(small) / 1e6,
+                        sorted(small)[len(small) // 2] / 1e3 if small else 0.0, len(gs) - len(small), (sum(gs) - sum(small)) / 1e6))
             if "--around" in sys.argv and gaps:
                 # the launches either side of the largest gap: start (ms into the window), duration (us), stream, name
                 t_gap = gaps[0][1] * 1e6 + part[0][1]
