@@ -288,7 +288,7 @@ def main():
 
     def sync():
         if world > 1:
-            dist.barrier()
+            mdist.barrier()
         torch.cuda.synchronize()
 
     pipe, side = build(args.workload, device)
@@ -411,7 +411,7 @@ def main():
             if roof is not None and args.workload == "unet64" and bf16 and batch == 64:
                 roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"])   # HBM bytes per launch (PMC), null if not collected
     if world > 1:
-        dist.barrier()
+        mdist.barrier()
 
     # BASELINE.json configs[2]: the nested 64+256 train step at batch 16, same protocol, fewer steps
     nested = None
@@ -584,7 +584,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, batch)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        mdist.barrier()
         dist.destroy_process_group()
 
 

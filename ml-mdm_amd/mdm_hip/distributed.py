@@ -75,8 +75,17 @@ def init_distributed_singlenode(timeout: int = 0, backend: str = None):
     if backend == "nccl":
         torch.cuda.set_device(local)
     dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank, **kw)
-    dist.barrier()
+    barrier(local)
     return local, rank, world
+
+
+def barrier(local_rank: int = None):
+    """dist.barrier() that tells RCCL which device this rank uses (without it ProcessGroupNCCL guesses rank % device count
+    and warns that a heterogeneous mapping can hang)"""
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[torch.cuda.current_device() if local_rank is None else local_rank])
+    else:
+        dist.barrier()
 
 
 class GradReducer:
