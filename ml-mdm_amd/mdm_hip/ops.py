@@ -198,6 +198,7 @@ def join_side_stream():
 
 
 _side_record_stream = os.environ.get("MDM_HIP_RECORD_STREAM", "0") == "1"   # development A/B: the old belt-and-braces form
+_late_wgrad_first = os.environ.get("MDM_HIP_LATE_WGRAD_FIRST", "1") != "0"     # development A/B (SharedInputLinearsFn.backward)
 
 
 def _off_critical_path(tensors, fn):
@@ -1276,12 +1277,16 @@ class TextKVFn(torch.autograd.Function):
                for l, d in enumerate(dys)]
         dcn = [torch.empty_like(cond) for _ in range(L)]
         grads = [None] * (4 * L)
-        for cout, idx in groups.items():
+        def dgrad(cout, idx):
             packs = [packed_weight(ws[l], bs[l], cond.dtype) for l in idx]
             _prof_wrap("linear grouped x%d M=%d N=%d K=%d" % (len(idx), R, D, cout), 2.0 * len(idx) * R * cout * D, lambda: _lib.check(
                 lib.mdm_linear_grouped(_ptr_array([dys[l] for l in idx]), _ptr_array([pk[1] for pk in packs]), None,
                                        _ptr_array([dcn[l] for l in idx]), len(idx), R, cout, D, _dt(cond), _stream()),
                 "mdm_linear_grouped"))
+
+        for cout, idx in groups.items():
+            if not _late_wgrad_first:   # (see SharedInputLinearsFn.backward: the weight gradients are handed over first)
+                dgrad(cout, idx)
             # weight / bias gradients: one grouped launch, into the gradient arena when there is one
             slots = [(_slot(ws[l]), _slot(bs[l])) for l in idx]
             sunk = all(a is not None and b is not None for a, b in slots)
@@ -1306,6 +1311,9 @@ class TextKVFn(torch.autograd.Function):
                 go()
                 for k, l in enumerate(idx):
                     grads[4 * l + 2], grads[4 * l + 3] = dws[k], dbs[k]
+        if _late_wgrad_first:
+            for cout, idx in groups.items():
+                dgrad(cout, idx)
         g32 = [_c(t.detach().float()) for t in lnw]
         nslots = [(_slot(lnw[l]), _slot(lnb[l])) for l in range(L)]
         nsunk = all(a is not None and b is not None for a, b in nslots)
@@ -1365,11 +1373,18 @@ class SharedInputLinearsFn(torch.autograd.Function):
         dys = [_c(d) if d is not None else torch.zeros((R, ws[l].shape[0]), dtype=x.dtype, device=x.device) for l, d in enumerate(dys)]
         dxs = [torch.empty_like(x) for _ in range(L)]
         grads = [None] * (2 * L)
-        for cout, idx in groups.items():
+        def dgrad(cout, idx):
             packs = [packed_weight(ws[l], bs[l], x.dtype) for l in idx]
             _lib.check(lib.mdm_linear_grouped(_ptr_array([dys[l] for l in idx]), _ptr_array([pk[1] for pk in packs]), None,
                                               _ptr_array([dxs[l] for l in idx]), len(idx), R, cout, D, _dt(x), _stream()),
                        "mdm_linear_grouped")
+
+        # These layers' gradients arrive when backward ENDS: nothing of the main stream is left to hide behind.  The weight
+        # gradients (side stream) are handed over BEFORE the input-gradient launches, so that they wait for what precedes
+        # those, not for them (the hand-off makes the side stream wait for everything queued on the main stream so far).
+        for cout, idx in groups.items():
+            if not _late_wgrad_first:
+                dgrad(cout, idx)
             slots = [(_slot(ws[l]), _slot(bs[l])) for l in idx]
             sunk = all(a is not None and b is not None for a, b in slots)
             if sunk:
@@ -1392,6 +1407,9 @@ class SharedInputLinearsFn(torch.autograd.Function):
                 go()
                 for k, l in enumerate(idx):
                     grads[2 * l], grads[2 * l + 1] = dws[k], dbs[k]
+        if _late_wgrad_first:
+            for cout, idx in groups.items():
+                dgrad(cout, idx)
         dx = dxs[0] if L == 1 else torch.stack(dxs).sum(0)
         return (dx,) + tuple(grads)
 
