@@ -14,7 +14,10 @@ from mdm_hip import _lib  # noqa: E402
 def main():
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 461_000_000 // 4 * 4
     dev = torch.device("cuda:0")
-    p, g, m, v, e = (torch.randn(n, device=dev) * 0.01 for _ in range(5))
+    skew = int(os.environ.get("ADAM_SKEW_BYTES", "0")) // 4   # development: shift array k by k * skew bytes (channel / bank alignment)
+    bufs = [torch.randn(n + 5 * skew, device=dev) * 0.01 for _ in range(5)]
+    p, g, m, v, e = (b[k * skew:k * skew + n] for k, b in enumerate(bufs))
+    print("base addresses mod 1 MiB:", [hex(t.data_ptr() % (1 << 20)) for t in (p, g, m, v, e)])
     v.abs_()
     q = torch.ones(1, device=dev)
     L = _lib.lib()
